@@ -1,0 +1,247 @@
+"""ctypes/numpy binding of the CPU oracle (oracle/nso.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Never imported by the product package.  Parity status: see the header of nso.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+STAGES = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
+LEVELS = ("coarse", "middle", "fine", "color")
+
+
+def build(force=False):
+    libs = [os.path.join(_HERE, "libnso_f32.so"), os.path.join(_HERE, "libnso_f64.so")]
+    src = os.path.join(_HERE, "nso.c")
+    if force or any(not os.path.exists(l) or os.path.getmtime(l) < os.path.getmtime(src) for l in libs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    return libs
+
+
+class _Opts(C.Structure):
+    pass
+
+
+class _Grid(C.Structure):
+    pass
+
+
+def _stage_id(stage):
+    return STAGES[stage] if isinstance(stage, str) else int(stage)
+
+
+class Oracle:
+    """One precision variant of the oracle: Oracle('f32') mirrors the reference's fp32 math,
+    Oracle('f64') is the same restatement in double."""
+
+    def __init__(self, prec="f32"):
+        build()
+        self.dt = np.float32 if prec == "f32" else np.float64
+        self.creal = C.c_float if prec == "f32" else C.c_double
+        self.lib = C.CDLL(os.path.join(_HERE, "libnso_%s.so" % prec))
+        assert self.lib.nso_real_size() == np.dtype(self.dt).itemsize
+        R = self.creal
+
+        class Opts(C.Structure):
+            _fields_ = [("bound", R * 6), ("n_samples", C.c_int), ("n_surface", C.c_int), ("lindisp", C.c_int),
+                        ("perturb", R), ("occupancy", C.c_int), ("seed", C.c_uint64)]
+
+        class Grid(C.Structure):
+            _fields_ = [("C", C.c_int), ("Z", C.c_int), ("Y", C.c_int), ("X", C.c_int), ("v", C.c_void_p)]
+
+        self.Opts, self.Grid = Opts, Grid
+        self.lib.nso_decoder_param_count.restype = C.c_long
+        self.lib.nso_depth_max.restype = R
+        self.lib.nso_loss_map.restype = R
+        self.lib.nso_loss_track.restype = R
+        self.lib.nso_inside_filter.restype = C.c_int
+
+    # -- helpers ---------------------------------------------------------------------------
+    def arr(self, x, shape=None):
+        a = np.ascontiguousarray(np.asarray(x, dtype=self.dt))
+        if shape is not None:
+            a = a.reshape(shape)
+        return a
+
+    @staticmethod
+    def _p(a):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+    def opts(self, bound, n_samples=32, n_surface=16, lindisp=False, perturb=0.0, occupancy=False, seed=0):
+        o = self.Opts()
+        b = np.asarray(bound, dtype=self.dt).reshape(6)
+        for i in range(6):
+            o.bound[i] = b[i]
+        o.n_samples, o.n_surface, o.lindisp = n_samples, n_surface, int(lindisp)
+        o.perturb, o.occupancy, o.seed = perturb, int(occupancy), seed
+        return o
+
+    def param_count(self, which):
+        return int(self.lib.nso_decoder_param_count(_stage_id(which)))
+
+    def _grids(self, grids):
+        """grids: dict level-name -> ndarray [C,Z,Y,X] (or [1,C,Z,Y,X]). Returns (ctypes array, keepalive)."""
+        arr = (self.Grid * 4)()
+        keep = []
+        for i, name in enumerate(LEVELS):
+            if name in grids and grids[name] is not None:
+                g = self.arr(grids[name])
+                if g.ndim == 5:
+                    g = g[0]
+                keep.append(g)
+                arr[i].C, arr[i].Z, arr[i].Y, arr[i].X = g.shape
+                arr[i].v = g.ctypes.data
+            else:
+                arr[i].C = arr[i].Z = arr[i].Y = arr[i].X = 0
+                arr[i].v = None
+        return arr, keep
+
+    def _decs(self, decoders):
+        ptrs = (C.c_void_p * 4)()
+        keep = []
+        for i, name in enumerate(LEVELS):
+            if name in decoders and decoders[name] is not None:
+                d = self.arr(decoders[name]).reshape(-1)
+                assert d.size == self.param_count(i), (name, d.size, self.param_count(i))
+                keep.append(d)
+                ptrs[i] = d.ctypes.data
+            else:
+                ptrs[i] = None
+        return ptrs, keep
+
+    # -- render ----------------------------------------------------------------------------
+    def render_forward(self, opts, grids, decoders, stage, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0,
+                       want_aux=False):
+        ro, rd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3))
+        N = ro.shape[0]
+        gd = None if gt_depth is None else self.arr(gt_depth, (N,))
+        S = opts.n_samples + (opts.n_surface if gd is not None else 0)
+        rgb, depth, var = np.zeros((N, 3), self.dt), np.zeros(N, self.dt), np.zeros(N, self.dt)
+        w = np.zeros((N, S), self.dt)
+        z = np.zeros((N, S), self.dt) if want_aux else None
+        raw = np.zeros((N, S, 4), self.dt) if want_aux else None
+        ga, k1 = self._grids(grids)
+        da, k2 = self._decs(decoders)
+        rc = self.lib.nso_render_forward(C.byref(opts), ga, da, _stage_id(stage), N, self._p(ro), self._p(rd),
+                                         self._p(gd), self.creal(gt_depth_max), self._p(rgb), self._p(depth),
+                                         self._p(var), self._p(w), self._p(z), self._p(raw))
+        assert rc == 0
+        out = dict(rgb=rgb, depth=depth, var=var, weights=w)
+        if want_aux:
+            out.update(z=z, raw=raw)
+        return out
+
+    def render_backward(self, opts, grids, decoders, stage, rays_o, rays_d, gt_depth, gt_depth_max, g_rgb, g_depth,
+                        g_var=None, want_grids=True, want_decoders=True, want_rays=True):
+        ro, rd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3))
+        N = ro.shape[0]
+        gd = None if gt_depth is None else self.arr(gt_depth, (N,))
+        grgb, gdep = self.arr(g_rgb, (N, 3)), self.arr(g_depth, (N,))
+        gvar = None if g_var is None else self.arr(g_var, (N,))
+        ga, k1 = self._grids(grids)
+        da, k2 = self._decs(decoders)
+        gg_ptr, gp_ptr = (C.c_void_p * 4)(), (C.c_void_p * 4)()
+        gg, gp = {}, {}
+        for i, name in enumerate(LEVELS):
+            if want_grids and ga[i].v:
+                gg[name] = np.zeros((ga[i].C, ga[i].Z, ga[i].Y, ga[i].X), self.dt)
+                gg_ptr[i] = gg[name].ctypes.data
+            if want_decoders and da[i]:
+                gp[name] = np.zeros(self.param_count(i), self.dt)
+                gp_ptr[i] = gp[name].ctypes.data
+        gro = np.zeros((N, 3), self.dt) if want_rays else None
+        grd = np.zeros((N, 3), self.dt) if want_rays else None
+        rc = self.lib.nso_render_backward(C.byref(opts), ga, da, _stage_id(stage), N, self._p(ro), self._p(rd),
+                                          self._p(gd), self.creal(gt_depth_max), self._p(grgb), self._p(gdep),
+                                          self._p(gvar), gg_ptr if want_grids else None,
+                                          gp_ptr if want_decoders else None, self._p(gro), self._p(grd))
+        assert rc == 0
+        return dict(g_grids=gg, g_decoders=gp, g_rays_o=gro, g_rays_d=grd)
+
+
+    def ray_fragility(self, opts, grids, decoders, stage, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0):
+        """min |ReLU input| per ray (test aid, see nso.c)"""
+        ro, rd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3))
+        N = ro.shape[0]
+        gd = None if gt_depth is None else self.arr(gt_depth, (N,))
+        ga, k1 = self._grids(grids)
+        da, k2 = self._decs(decoders)
+        frag = np.zeros(N, self.dt)
+        rc = self.lib.nso_ray_fragility(C.byref(opts), ga, da, _stage_id(stage), N, self._p(ro), self._p(rd),
+                                        self._p(gd), self.creal(gt_depth_max), self._p(frag))
+        assert rc == 0
+        return frag
+
+    # -- losses ----------------------------------------------------------------------------
+    def loss_map(self, depth, rgb, gt_depth, gt_color, w_color, use_color):
+        d, c, gd, gc = self.arr(depth), self.arr(rgb, (-1, 3)), self.arr(gt_depth), self.arr(gt_color, (-1, 3))
+        N = d.shape[0]
+        g_d, g_c = np.zeros(N, self.dt), np.zeros((N, 3), self.dt)
+        loss = self.lib.nso_loss_map(N, self._p(d), self._p(c), self._p(gd), self._p(gc), self.creal(w_color),
+                                     int(use_color), self._p(g_d), self._p(g_c))
+        return float(loss), g_d, g_c
+
+    def loss_track(self, depth, rgb, var, gt_depth, gt_color, w_color, use_color, handle_dynamic, detach_var=True):
+        d, c, v = self.arr(depth), self.arr(rgb, (-1, 3)), self.arr(var)
+        gd, gc = self.arr(gt_depth), self.arr(gt_color, (-1, 3))
+        N = d.shape[0]
+        g_d, g_c, g_v = np.zeros(N, self.dt), np.zeros((N, 3), self.dt), np.zeros(N, self.dt)
+        loss = self.lib.nso_loss_track(N, self._p(d), self._p(c), self._p(v), self._p(gd), self._p(gc),
+                                       self.creal(w_color), int(use_color), int(handle_dynamic), int(detach_var),
+                                       self._p(g_d), self._p(g_c), self._p(g_v))
+        return float(loss), g_d, g_c, g_v
+
+    def adam_step(self, p, g, m, v, lr, step, mask=None, b1=0.9, b2=0.999, eps=1e-8):
+        """in place on p, m, v (must be contiguous arrays of this oracle's dtype)"""
+        for a in (p, m, v):
+            assert a.dtype == self.dt and a.flags.c_contiguous
+        g = self.arr(g)
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.lib.nso_adam_step(C.c_long(p.size), self._p(p), self._p(g), self._p(m), self._p(v), self._p(mk),
+                               self.creal(lr), self.creal(b1), self.creal(b2), self.creal(eps), int(step))
+
+    # -- pose / rays -----------------------------------------------------------------------
+    def camera_from_tensor(self, cam):
+        c = self.arr(cam, (7,))
+        out = np.zeros((3, 4), self.dt)
+        self.lib.nso_camera_from_tensor(self._p(c), self._p(out))
+        return out
+
+    def camera_backward(self, cam, g_c2w):
+        c, g = self.arr(cam, (7,)), self.arr(g_c2w, (3, 4))
+        out = np.zeros(7, self.dt)
+        self.lib.nso_camera_backward(self._p(c), self._p(g), self._p(out))
+        return out
+
+    def rays_from_pixels(self, pix_i, pix_j, fx, fy, cx, cy, c2w, mode=0):
+        pi = np.ascontiguousarray(pix_i, dtype=np.int32)
+        pj = np.ascontiguousarray(pix_j, dtype=np.int32)
+        n = pi.size
+        m = self.arr(c2w)[:3, :4].copy()
+        ro, rd = np.zeros((n, 3), self.dt), np.zeros((n, 3), self.dt)
+        R = self.creal
+        self.lib.nso_rays_from_pixels(n, self._p(pi), self._p(pj), R(fx), R(fy), R(cx), R(cy), self._p(m), mode,
+                                      self._p(ro), self._p(rd))
+        return ro, rd
+
+    def rays_backward(self, pix_i, pix_j, fx, fy, cx, cy, g_rays_o, g_rays_d, mode=0):
+        pi = np.ascontiguousarray(pix_i, dtype=np.int32)
+        pj = np.ascontiguousarray(pix_j, dtype=np.int32)
+        n = pi.size
+        go, gd = self.arr(g_rays_o, (n, 3)), self.arr(g_rays_d, (n, 3))
+        out = np.zeros((3, 4), self.dt)
+        R = self.creal
+        self.lib.nso_rays_backward(n, self._p(pi), self._p(pj), R(fx), R(fy), R(cx), R(cy), mode, self._p(go),
+                                   self._p(gd), self._p(out))
+        return out
+
+    def inside_filter(self, bound, rays_o, rays_d, gt_depth):
+        b = self.arr(bound, (6,))
+        ro, rd, gd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3)), self.arr(gt_depth)
+        keep = np.zeros(ro.shape[0], np.uint8)
+        self.lib.nso_inside_filter(self._p(b), ro.shape[0], self._p(ro), self._p(rd), self._p(gd), self._p(keep))
+        return keep.astype(bool)

@@ -1,0 +1,189 @@
+/*
+ * nsk.h -- C-ABI of the MI355X-native NICE-SLAM render / map / track hot path ("neural slam kernels").
+ *
+ * This is the drop-in boundary.  The reference exposes no FFI layer: its boundary is the
+ * C++ class surface of include/Renderer.h:11-13, include/Mapper.h:20-25, include/Tracker.h:11-15 and
+ * include/models/NICE.h:6-7, all of which hand libtorch tensors to stock libtorch ops.  The entry points below
+ * are what thin Renderer / NICE / Mapper / Tracker classes with those exact signatures marshal into
+ * (nice-slam-cpp_amd/host/); every entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch types.  `d_` pointers are device (HIP) pointers, `h_` pointers are host pointers.
+ *   - the caller owns every buffer it passes; the context owns grids, decoder parameters, their gradients
+ *     and the Adam moments.
+ *   - every function returns 0 on success, <0 on error; nsk_last_error() gives a thread-local message.
+ *     (The reference defines no error behaviour: libtorch c10::Error exceptions propagate out of main.)
+ *   - one nsk_ctx = one GPU + one HIP stream.  Calls are asynchronous on that stream unless stated; a context
+ *     is not thread-safe, different contexts may be driven from different threads.
+ *   - levels / stages / decoders share ids: 0 coarse, 1 middle, 2 fine, 3 color (src/models/NICE.cpp:16-52).
+ *   - all arithmetic is fp32 (the reference's dtype); tolerance contract: 1e-4 relative L2 on rendered
+ *     depth / colour and on optimised grids / poses.
+ */
+#ifndef NSK_H
+#define NSK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSK_COARSE 0
+#define NSK_MIDDLE 1
+#define NSK_FINE 2
+#define NSK_COLOR 3
+
+/* nsk_render_backward / nsk_map_step `flags` */
+#define NSK_GRAD_GRIDS 1u     /* accumulate d loss / d grid features of the levels the stage reads         */
+#define NSK_GRAD_DECODERS 2u  /* accumulate d loss / d decoder parameters of decoders marked trainable     */
+#define NSK_GRAD_RAYS 4u      /* write d loss / d rays_o, d loss / d rays_d (Tracker, BA)                  */
+
+/* Adam parameter groups, in the order of torch::optim::Adam's groups at src/Mapper.cpp:330 */
+#define NSK_GROUP_DECODERS 0
+#define NSK_GROUP_COARSE 1
+#define NSK_GROUP_MIDDLE 2
+#define NSK_GROUP_FINE 3
+#define NSK_GROUP_COLOR 4
+#define NSK_GROUP_CAMERA 5
+#define NSK_NUM_GROUPS 6
+
+typedef struct nsk_ctx nsk_ctx;
+
+const char* nsk_last_error(void);
+int nsk_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+/* Replaces the 33 hard-coded torch::Device(torch::kCUDA,0) sites (e.g. src/Renderer.cpp:31,69,76).
+ * hip_stream: a hipStream_t to launch on (NULL = the context creates its own non-blocking stream). */
+int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out);
+int nsk_ctx_destroy(nsk_ctx* ctx);
+int nsk_sync(nsk_ctx* ctx);                         /* hipStreamSynchronize */
+void* nsk_stream(nsk_ctx* ctx);                     /* the hipStream_t in use */
+
+/* Scene bound [[x0,x1],[y0,y1],[z0,z1]]; the reference hard-codes it in five places
+ * (src/main.cpp:33, src/Renderer.cpp:15, src/Mapper.cpp:29, src/Tracker.cpp:23, src/models/MLP.cpp:53-56). */
+int nsk_set_bound(nsk_ctx* ctx, const float h_bound[6]);
+
+/* Renderer::Renderer() constants (src/Renderer.cpp:5-15): N_samples 32, N_surface 16, lindisp false, perturb 0,
+ * occupancy: 0 = the density branch the reference executes (src/Renderer.cpp:125 passes false, utils.h:155-157),
+ * 1 = alpha = sigmoid(10 sigma).  n_samples + n_surface <= 64. */
+int nsk_set_render_opts(nsk_ctx* ctx, int n_samples, int n_surface, int lindisp, float perturb, int occupancy,
+                        uint64_t seed);
+
+/* ---- feature grids: c10::Dict<string,Tensor> "grid_<level>" [1,C,Z,Y,X] fp32 (src/main.cpp:33-78) ------ */
+/* h_czyx is the reference layout [C][Z][Y][X] (C must be 32); the device copy is voxel-major [Z][Y][X][C]
+ * so that the 32 channels of a voxel are one 128-byte line (conversion happens here). */
+int nsk_grid_upload(nsk_ctx* ctx, int level, const float* h_czyx, int C, int Z, int Y, int X);
+int nsk_grid_download(nsk_ctx* ctx, int level, float* h_czyx);
+int nsk_grid_grad_download(nsk_ctx* ctx, int level, float* h_czyx);
+/* frustum feature selection (src/Mapper.cpp:254-290,333-350): h_mask_zyx[Z*Y*X] != 0 marks voxels that are
+ * optimiser parameters; NULL = all voxels.  Gradients of unmarked voxels are discarded. */
+int nsk_set_mask(nsk_ctx* ctx, int level, const uint8_t* h_mask_zyx);
+
+/* ---- decoders (src/models/MLP.cpp:3-49,104-138; src/models/GaussianFFT.cpp:3-8) -------------------------- */
+/* packed parameter order (row-major [out,in] as torch::nn::Linear):
+ *   middle/fine/color: B[3][93], pts_linear[0..4].{weight,bias}, fc[0..4].{weight,bias}, output_linear.{weight,bias}
+ *   coarse:            pts_linear[0..4].{weight,bias}, output_linear.{weight,bias}
+ * counts: coarse 6337, middle 15800, fine 20920, color 15899. */
+size_t nsk_decoder_param_count(int which);
+int nsk_decoder_upload(nsk_ctx* ctx, int which, const float* h_packed, size_t n);
+int nsk_decoder_download(nsk_ctx* ctx, int which, float* h_packed, size_t n);
+int nsk_decoder_grad_download(nsk_ctx* ctx, int which, float* h_packed, size_t n);
+/* which decoders receive gradients / Adam updates (src/Mapper.cpp:292-301: fine if !fix_fine, color if !fix_color) */
+int nsk_decoder_set_trainable(nsk_ctx* ctx, int which, int trainable);
+
+/* ---- rendering ------------------------------------------------------------------------------------------ */
+/* Renderer::render_batch_ray (src/Renderer.cpp:44-126) = z sampling + Renderer::eval_points (:19-42) +
+ * NICE::forward (src/models/NICE.cpp:16-52) + raw2outputs_nerf_color (include/torchlib/utils.h:148-172).
+ *   d_rays_o, d_rays_d [N][3]; d_gt_depth [N] or NULL (then N_surface = 0, :54-57);
+ *   gt_depth_max: max over the WHOLE batch of gt_depth (:76,:93).  Pass < 0 to have it computed on the device
+ *   from d_gt_depth; multi-GPU callers pass the global maximum so that sharding rays does not change results.
+ *   outputs: d_rgb [N][3], d_depth [N], d_var [N], d_weights [N][S] or NULL (S = n_samples (+ n_surface)). */
+int nsk_render_forward(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d,
+                       const float* d_gt_depth, float gt_depth_max, float* d_rgb, float* d_depth, float* d_var,
+                       float* d_weights);
+
+/* Renderer::eval_points (src/Renderer.cpp:19-42): raw [M][4] = (rgb, occupancy) of M points, occupancy = 100
+ * outside the bound. */
+int nsk_eval_points(nsk_ctx* ctx, int stage, int M, const float* d_points, float* d_raw);
+
+/* Backward of render_batch_ray given upstream gradients (what loss.backward() at src/Mapper.cpp:444 /
+ * src/Tracker.cpp:84 is meant to do).  The forward is recomputed internally.
+ *   d_g_rgb [N][3], d_g_depth [N], d_g_var [N] or NULL (depth_var detached).
+ *   Gradients ACCUMULATE into the context-owned gradient slab (grids, trainable decoders) until nsk_adam_step
+ *   or nsk_zero_grads; d_g_rays_o / d_g_rays_d [N][3] are overwritten (NSK_GRAD_RAYS). */
+int nsk_render_backward(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d,
+                        const float* d_gt_depth, float gt_depth_max, const float* d_g_rgb, const float* d_g_depth,
+                        const float* d_g_var, unsigned flags, float* d_g_rays_o, float* d_g_rays_d);
+
+/* One mapping iteration without the Adam step: render forward, Mapper loss (src/Mapper.cpp:435-442:
+ * sum_{gt>0}|gt_d - d| + use_color * w_color * sum|gt_c - c|) and backward, fused so that the loss gradient
+ * never leaves the GPU.  d_loss (device float, may be NULL) receives the loss; outputs d_rgb/d_depth/d_var may
+ * be NULL. */
+int nsk_map_step(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d,
+                 const float* d_gt_depth, const float* d_gt_color, float gt_depth_max, float w_color, int use_color,
+                 unsigned flags, float* d_loss, float* d_rgb, float* d_depth, float* d_var, float* d_g_rays_o,
+                 float* d_g_rays_d);
+
+/* One tracking iteration without the Adam step (src/Tracker.cpp:41-89): render, dynamic-outlier mask
+ * |gt_d - d| < 10 median (:67-71), loss sum_mask |gt_d - d| / sqrt(var + 1e-10) + w_color sum_mask |gt_c - c|
+ * (:75-82), backward onto the rays.  detach_var: treat depth_var as a constant. */
+int nsk_track_step(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d,
+                   const float* d_gt_depth, const float* d_gt_color, float gt_depth_max, float w_color, int use_color,
+                   int handle_dynamic, int detach_var, unsigned flags, float* d_loss, float* d_g_rays_o,
+                   float* d_g_rays_d);
+
+/* Stand-alone losses with seed gradients (same formulas as above) for callers that drive
+ * nsk_render_forward / nsk_render_backward themselves. */
+int nsk_loss_map(nsk_ctx* ctx, int N, const float* d_depth, const float* d_rgb, const float* d_gt_depth,
+                 const float* d_gt_color, float w_color, int use_color, float* d_g_depth, float* d_g_rgb,
+                 float* d_loss);
+int nsk_loss_track(nsk_ctx* ctx, int N, const float* d_depth, const float* d_rgb, const float* d_var,
+                   const float* d_gt_depth, const float* d_gt_color, float w_color, int use_color, int handle_dynamic,
+                   int detach_var, float* d_g_depth, float* d_g_rgb, float* d_g_var, float* d_loss);
+
+/* ---- rays and pose (include/torchlib/utils.h:13-55,141-146,174-210; src/Mapper.cpp:416-427) ------------- */
+/* raySampler's direction/origin part for given pixel indices (the reference draws them with torch::randint,
+ * utils.h:32; streams cannot match, so indices are an input).  d_c2w: 12 floats, row-major [3][4].
+ * mode bit0: as-written j_t=(i-cy)/fy without sign flip (D11); bit1: truncate intrinsics to int (D10);
+ * 0 = intended OpenGL camera dirs=[(i-cx)/fx, -(j-cy)/fy, -1]. */
+int nsk_rays_from_pixels(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy,
+                         float cx, float cy, const float* d_c2w, int mode, float* d_rays_o, float* d_rays_d);
+/* d loss / d c2w (12 floats, overwritten) from per-ray gradients */
+int nsk_rays_backward(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy,
+                      float cx, float cy, int mode, const float* d_g_rays_o, const float* d_g_rays_d, float* d_g_c2w);
+/* get_camera_from_tensor / quad2rotation (utils.h:174-210): cam = (qw,qx,qy,qz,tx,ty,tz) -> c2w [3][4] */
+int nsk_camera_from_tensor(nsk_ctx* ctx, const float* d_cam, float* d_c2w);
+int nsk_camera_backward(nsk_ctx* ctx, const float* d_cam, const float* d_g_c2w, float* d_g_cam);
+/* inside-bbox pre-filter (src/Mapper.cpp:416-427, src/Tracker.cpp:48-58): d_keep[n] = (t >= gt_depth) */
+int nsk_inside_filter(nsk_ctx* ctx, int N, const float* d_rays_o, const float* d_rays_d, const float* d_gt_depth,
+                      uint8_t* d_keep);
+/* plain Adam on a caller-owned vector (camera 7-vectors: src/Tracker.cpp:103, src/Mapper.cpp:305-329) */
+int nsk_adam_vector(nsk_ctx* ctx, int n, float* d_p, const float* d_g, float* d_m, float* d_v, float lr, float beta1,
+                    float beta2, float eps, int step);
+
+/* ---- optimiser (torch::optim::Adam, src/Mapper.cpp:330,360-368,445-446) ---------------------------------- */
+/* lr[g] for NSK_GROUP_*; groups whose gradients were produced since the last step are updated (an lr of 0
+ * still advances their moments, as torch does); gradients are zeroed afterwards (optimizer.zero_grad(), :446).
+ * Only masked voxels move (nsk_set_mask).  nsk_adam_reset drops the moments and step counts (the reference
+ * re-creates the optimiser on every optimize_map call, :330). */
+int nsk_adam_step(nsk_ctx* ctx, const float lr[NSK_NUM_GROUPS], float beta1, float beta2, float eps);
+int nsk_adam_reset(nsk_ctx* ctx);
+int nsk_zero_grads(nsk_ctx* ctx);
+
+/* ---- multi-GPU ------------------------------------------------------------------------------------------- */
+/* The gradient slab (all grid gradients, all decoder gradients, one loss scalar) is one contiguous device
+ * buffer so that a mapping step needs exactly one all-reduce. */
+int nsk_grad_slab(nsk_ctx* ctx, float** d_ptr, size_t* n_floats);
+/* ncclAllReduce(sum, fp32) of the slab on the context's stream; comm is an ncclComm_t (RCCL). */
+int nsk_allreduce_grads(nsk_ctx* ctx, void* nccl_comm);
+
+/* ---- introspection for benchmarks ------------------------------------------------------------------------ */
+/* algorithmic bytes / flops of the last render or step call (SURVEY.md section 8d accounting) */
+int nsk_last_call_stats(nsk_ctx* ctx, double* alg_bytes, double* alg_flops, int* samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSK_H */

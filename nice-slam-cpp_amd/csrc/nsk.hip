@@ -1,0 +1,1046 @@
+// nsk.hip -- C-ABI (include/nsk.h) of the MI355X-native NICE-SLAM hot path: context, data layouts, launches.
+// Built only for gfx950:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC nsk.hip -o libnsk.so
+#include "../../include/nsk.h"
+#include "nsk_device.h"
+
+#include <dlfcn.h>
+#include <cstdarg>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define NSK_VERSION 100
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return -1;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define CHK(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// small kernels that only the host file needs
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_pack(float* __restrict__ img, const int* __restrict__ idx, const float* __restrict__ P, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { int k = idx[i]; img[i] = k >= 0 ? P[k] : 0.f; }
+}
+
+// torch::optim::Adam (reference src/Mapper.cpp:330,445-446); mask is per voxel (32 floats) or nullptr; zeroes g
+__global__ void k_adam(int n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       const uint8_t* __restrict__ mask, float step_size, float bc2s, float b1, float b2, float eps)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;       // one f4 per thread
+    if (4 * i >= n) return;
+    f4* g4 = reinterpret_cast<f4*>(g) + i;
+    if (mask && !mask[i >> 3]) { *g4 = (f4)(0.f); return; }
+    f4 gg = *g4, pp = reinterpret_cast<f4*>(p)[i], mm = reinterpret_cast<f4*>(m)[i], vv = reinterpret_cast<f4*>(v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+        vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+        float denom = sqrtf(vv[k]) / bc2s + eps;
+        pp[k] -= step_size * (mm[k] / denom);
+    }
+    reinterpret_cast<f4*>(p)[i] = pp; reinterpret_cast<f4*>(m)[i] = mm; reinterpret_cast<f4*>(v)[i] = vv;
+    *g4 = (f4)(0.f);
+}
+
+__global__ void k_adam_scalar(int n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                              float* __restrict__ v, float step_size, float bc2s, float b1, float b2, float eps)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gg = g[i];
+    float mm = b1 * m[i] + (1.f - b1) * gg;
+    float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    p[i] -= step_size * (mm / (sqrtf(vv) / bc2s + eps));
+    m[i] = mm; v[i] = vv;
+}
+
+__global__ void k_sum(int n, const float* __restrict__ x, float* __restrict__ out)
+{
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += sh[w]; *out = s; }
+}
+
+// Mapper loss, reference src/Mapper.cpp:435-442
+__global__ void k_loss_map(int N, const float* depth, const float* rgb, const float* gt_d, const float* gt_c, float w_color,
+                           int use_color, float* g_depth, float* g_rgb, float* ray_loss)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float l = 0.f, g = 0.f;
+    if (gt_d[n] > 0.f) { float r = gt_d[n] - depth[n]; l += fabsf(r); g = -sgnf(r); }
+    g_depth[n] = g;
+    for (int k = 0; k < 3; ++k) {
+        float r = gt_c[3 * n + k] - rgb[3 * n + k];
+        if (use_color) { l += w_color * fabsf(r); g_rgb[3 * n + k] = -w_color * sgnf(r); }
+        else g_rgb[3 * n + k] = 0.f;
+    }
+    ray_loss[n] = l;
+}
+
+// Tracker loss, reference src/Tracker.cpp:67-82
+__global__ void k_loss_track(int N, const float* depth, const float* rgb, const float* var, const float* gt_d, const float* gt_c,
+                             float w_color, int use_color, int handle_dynamic, int detach_var, const float* thr,
+                             float* g_depth, float* g_rgb, float* g_var, float* ray_loss)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float r = gt_d[n] - depth[n];
+    bool mk = gt_d[n] > 0.f && (!handle_dynamic || fabsf(r) < *thr);
+    float l = 0.f, gd = 0.f, gv = 0.f, gc[3] = {0.f, 0.f, 0.f};
+    if (mk) {
+        float u = sqrtf(var[n] + 1e-10f);
+        l = fabsf(r) / u; gd = -sgnf(r) / u;
+        if (!detach_var) gv = -fabsf(r) / (2.f * u * u * u);
+        if (use_color) for (int k = 0; k < 3; ++k) { float rc = gt_c[3 * n + k] - rgb[3 * n + k]; l += w_color * fabsf(rc); gc[k] = -w_color * sgnf(rc); }
+    }
+    g_depth[n] = gd; if (g_var) g_var[n] = gv;
+    for (int k = 0; k < 3; ++k) g_rgb[3 * n + k] = gc[k];
+    ray_loss[n] = l;
+}
+
+// 10 * torch.median(|gt - depth|) (lower median) by a single-workgroup bitonic sort in LDS
+__global__ __launch_bounds__(1024) void k_median_thr(int N, int P2, const float* gt_d, const float* depth, float* thr)
+{
+    extern __shared__ float shm[];
+    for (int i = threadIdx.x; i < P2; i += 1024) shm[i] = i < N ? fabsf(gt_d[i] - depth[i]) : NSK_INF;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += 1024) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    float a = shm[i], b = shm[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { shm[i] = b; shm[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) *thr = 10.f * shm[(N - 1) / 2];
+}
+
+// raySampler direction part, reference include/torchlib/utils.h:44-52
+__global__ void k_rays_from_pixels(int n, const int* pi, const int* pj, float fx, float fy, float cx, float cy, const float* c2w,
+                                   int mode, float* ro, float* rd)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float i = (float)pi[r], j = (float)pj[r];
+    float d0 = div_rn(sub_rn(i, cx), fx);
+    float d1 = (mode & 1) ? div_rn(sub_rn(i, cy), fy) : -div_rn(sub_rn(j, cy), fy);
+    float d2 = -1.f;
+    for (int a = 0; a < 3; ++a) {
+        rd[3 * r + a] = add_rn(add_rn(mul_rn(d0, c2w[4 * a]), mul_rn(d1, c2w[4 * a + 1])), mul_rn(d2, c2w[4 * a + 2]));
+        ro[3 * r + a] = c2w[4 * a + 3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rays_backward(int n, const int* pi, const int* pj, float fx, float fy, float cx, float cy,
+                                                       int mode, const float* g_ro, const float* g_rd, float* g_c2w)
+{
+    __shared__ float sh[4][12];
+    float acc[12];
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        float i = (float)pi[r], j = (float)pj[r];
+        float dir[3] = {(i - cx) / fx, (mode & 1) ? (i - cy) / fy : -(j - cy) / fy, -1.f};
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) acc[4 * a + b] += g_rd[3 * r + a] * dir[b];
+            acc[4 * a + 3] += g_ro[3 * r + a];
+        }
+    }
+    for (int k = 0; k < 12; ++k) { float s = wave_sum(acc[k]); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = s; }
+    __syncthreads();
+    if (threadIdx.x < 12) g_c2w[threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// quad2rotation / get_camera_from_tensor, reference include/torchlib/utils.h:174-210
+__global__ void k_camera_from_tensor(const float* cam, float* c2w)
+{
+    float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
+    float two_s = 2.f / (qr * qr + qi * qi + qj * qj + qk * qk);
+    float R[9] = {1.f - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+                  two_s * (qi * qj + qk * qr), 1.f - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qr),
+                  two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1.f - two_s * (qi * qi + qj * qj)};
+    for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) c2w[4 * a + b] = R[3 * a + b]; c2w[4 * a + 3] = cam[4 + a]; }
+}
+
+__global__ void k_camera_backward(const float* cam, const float* g_c2w, float* g_cam)
+{
+    float q[4] = {cam[0], cam[1], cam[2], cam[3]};
+    float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    float two_s = 2.f / n2;
+    float qr = q[0], qi = q[1], qj = q[2], qk = q[3];
+    float M[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr, qi * qj + qk * qr, -(qi * qi + qk * qk),
+                  qj * qk - qi * qr, qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)};
+    float dM[9][4] = {{0, 0, -2 * qj, -2 * qk}, {-qk, qj, qi, -qr}, {qj, qk, qr, qi}, {qk, qj, qi, qr}, {0, -2 * qi, 0, -2 * qk},
+                      {-qi, -qr, qk, qj}, {-qj, qk, -qr, qi}, {qi, qr, qk, qj}, {0, -2 * qi, -2 * qj, 0}};
+    for (int c = 0; c < 4; ++c) {
+        float dts = -2.f * two_s * q[c] / n2;
+        float s = 0.f;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) s += g_c2w[4 * a + b] * (dts * M[3 * a + b] + two_s * dM[3 * a + b][c]);
+        g_cam[c] = s;
+    }
+    for (int a = 0; a < 3; ++a) g_cam[4 + a] = g_c2w[4 * a + 3];
+}
+
+__global__ void k_inside_filter(RParams R, int N, const float* ro, const float* rd, const float* gt, uint8_t* keep)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    keep[n] = ray_box_far(R.bound, ro[3 * n], ro[3 * n + 1], ro[3 * n + 2], rd[3 * n], rd[3 * n + 1], rd[3 * n + 2]) >= gt[n];
+}
+
+// in-bound override for eval_points (reference src/Renderer.cpp:26-36)
+__global__ void k_eval_finish(int M, int stage, const float* pts, const float* bound6, const float* occ_a, const float* occ_b,
+                              const float* rgb4, float* raw)
+{
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float px = pts[3 * m], py = pts[3 * m + 1], pz = pts[3 * m + 2];
+    bool inb = px < bound6[1] && px > bound6[0] && py < bound6[3] && py > bound6[2] && pz < bound6[5] && pz > bound6[4];
+    float occ = occ_a[m];
+    if (occ_b) occ = occ_b[m] + occ;
+    f4 c = (f4)(0.f);
+    if (rgb4) c = *reinterpret_cast<const f4*>(rgb4 + (size_t)m * 4);
+    *reinterpret_cast<f4*>(raw + (size_t)m * 4) = (f4){c[0], c[1], c[2], inb ? occ : 100.f};
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------------
+struct GridState {
+    int C = 0, Z = 0, Y = 0, X = 0;
+    size_t n = 0;                // floats = nvox*32
+    float* v = nullptr; float* m = nullptr; float* s = nullptr;
+    uint8_t* mask = nullptr;
+    size_t g_off = 0;            // offset in the gradient slab
+};
+struct DecState {
+    int n = 0;
+    float* p = nullptr; float* m = nullptr; float* s = nullptr;
+    float* fimg = nullptr; float* bimg = nullptr;
+    int* fidx = nullptr; int* bidx = nullptr;
+    int fimg_n = 0, bimg_n = 0;
+    int trainable = 0;
+    bool loaded = false;
+    size_t g_off = 0;
+};
+struct Workspace {
+    int capM = 0, capN = 0;
+    float* z = nullptr; float* occ[3] = {nullptr, nullptr, nullptr}; float* rgb4 = nullptr;
+    unsigned long long* masks[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* g_raw = nullptr; float* ray_loss = nullptr;
+    float* tmp_rgb = nullptr; float* tmp_depth = nullptr; float* tmp_var = nullptr;
+};
+struct nsk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    RParams R;
+    float* d_bound = nullptr;
+    GridState grid[4];
+    DecState dec[4];
+    float* slab = nullptr; size_t slab_n = 0;
+    Workspace ws;
+    float* scal = nullptr;       // [0] gt max, [1] median threshold, [2] loss
+    int adam_step[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
+    bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
+    double last_bytes = 0, last_flops = 0; int last_samples = 0;
+};
+
+extern "C" const char* nsk_last_error(void) { return g_err.c_str(); }
+extern "C" int nsk_version(void) { return NSK_VERSION; }
+
+static int which_ok(int w) { return w >= 0 && w < 4; }
+
+template <typename K>
+static int set_lds(K kern, size_t bytes)
+{
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+static size_t fwd_img_floats(int w) { return w == 0 ? CoarseFwdImg::TOTAL : (w == 2 ? MlpFwdImg<4>::TOTAL : MlpFwdImg<2>::TOTAL); }
+static size_t bwd_img_floats(int w) { return w == 0 ? CoarseBwdImg::TOTAL : MlpBwdImg::TOTAL; }
+static size_t bwd_lds_bytes(int w, bool train)
+{
+    size_t scratch = 8 * 3840;
+    if (!train) return bwd_img_floats(w) * 4 + scratch;
+    size_t npar4 = (nsk_dec_layout(w).total + 3) & ~3;
+    size_t img = w == 2 ? 0 : fwd_img_floats(w);
+    return (img + npar4) * 4 + scratch;
+}
+
+extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
+{
+    if (!out) return fail("nsk_ctx_create: out is NULL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail("nsk_ctx_create: no HIP device (the MI355X kernels have no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("nsk_ctx_create: device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail("nsk_ctx_create: device arch %s, this library is built for gfx950 only", prop.gcnArchName);
+    nsk_ctx* c = new nsk_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    const float b[6] = {-4.5f, 3.82f, -1.5f, 2.02f, -3.0f, 2.76f};     // reference src/Renderer.cpp:15
+    memcpy(c->R.bound, b, sizeof(b));
+    c->R.n_samples = 32; c->R.n_surface = 16; c->R.lindisp = 0; c->R.occupancy = 0; c->R.perturb = 0.f; c->R.seed = 0;
+    HIPCHK(hipMalloc(&c->d_bound, 6 * sizeof(float)));
+    HIPCHK(hipMemcpy(c->d_bound, b, sizeof(b), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->scal, 16 * sizeof(float)));
+    HIPCHK(hipMemset(c->scal, 0, 16 * sizeof(float)));
+    // dynamic LDS limits
+    CHK(set_lds(k_decode_fwd<0>, fwd_img_floats(0) * 4)); CHK(set_lds(k_decode_fwd<1>, fwd_img_floats(1) * 4));
+    CHK(set_lds(k_decode_fwd<2>, fwd_img_floats(2) * 4)); CHK(set_lds(k_decode_fwd<3>, fwd_img_floats(3) * 4));
+#define SETB(W) \
+    CHK(set_lds(k_decode_bwd<W, false, false>, bwd_lds_bytes(W, false))); CHK(set_lds(k_decode_bwd<W, false, true>, bwd_lds_bytes(W, false))); \
+    CHK(set_lds(k_decode_bwd<W, true, false>, bwd_lds_bytes(W, true))); CHK(set_lds(k_decode_bwd<W, true, true>, bwd_lds_bytes(W, true)));
+    SETB(0) SETB(1) SETB(2) SETB(3)
+#undef SETB
+    CHK(set_lds(k_median_thr, 16384 * 4));
+    *out = c;
+    return 0;
+}
+
+static void free_ws(Workspace& w)
+{
+    hipFree(w.z); for (int i = 0; i < 3; ++i) hipFree(w.occ[i]); hipFree(w.rgb4);
+    for (int i = 0; i < 4; ++i) hipFree(w.masks[i]);
+    hipFree(w.g_raw); hipFree(w.ray_loss); hipFree(w.tmp_rgb); hipFree(w.tmp_depth); hipFree(w.tmp_var);
+    w = Workspace();
+}
+
+extern "C" int nsk_ctx_destroy(nsk_ctx* c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 4; ++i) {
+        hipFree(c->grid[i].v); hipFree(c->grid[i].m); hipFree(c->grid[i].s); hipFree(c->grid[i].mask);
+        hipFree(c->dec[i].p); hipFree(c->dec[i].m); hipFree(c->dec[i].s); hipFree(c->dec[i].fimg); hipFree(c->dec[i].bimg);
+        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx);
+    }
+    hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal);
+    free_ws(c->ws);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int nsk_sync(nsk_ctx* c) { if (!c) return fail("null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+extern "C" void* nsk_stream(nsk_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int nsk_set_bound(nsk_ctx* c, const float h_bound[6])
+{
+    if (!c || !h_bound) return fail("nsk_set_bound: null argument");
+    for (int k = 0; k < 3; ++k) if (!(h_bound[2 * k + 1] > h_bound[2 * k])) return fail("nsk_set_bound: empty axis %d", k);
+    memcpy(c->R.bound, h_bound, 6 * sizeof(float));
+    HIPCHK(hipMemcpyAsync(c->d_bound, c->R.bound, 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int nsk_set_render_opts(nsk_ctx* c, int n_samples, int n_surface, int lindisp, float perturb, int occupancy, uint64_t seed)
+{
+    if (!c) return fail("null ctx");
+    if (n_samples < 1 || n_surface < 0 || n_samples + n_surface > 64) return fail("nsk_set_render_opts: need 1 <= n_samples, n_samples+n_surface <= 64 (got %d+%d)", n_samples, n_surface);
+    c->R.n_samples = n_samples; c->R.n_surface = n_surface; c->R.lindisp = lindisp ? 1 : 0; c->R.perturb = perturb;
+    c->R.occupancy = occupancy ? 1 : 0; c->R.seed = seed;
+    return 0;
+}
+
+// gradient slab = [grid0..3 | dec0..3 | 4 floats (loss)]
+static int rebuild_slab(nsk_ctx* c)
+{
+    size_t n = 0;
+    for (int i = 0; i < 4; ++i) { c->grid[i].g_off = n; n += c->grid[i].n; }
+    for (int i = 0; i < 4; ++i) { c->dec[i].g_off = n; n += (size_t)((c->dec[i].n + 3) & ~3); }
+    n += 4;
+    if (n != c->slab_n) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->slab) HIPCHK(hipFree(c->slab));
+        HIPCHK(hipMalloc(&c->slab, n * sizeof(float)));
+        c->slab_n = n;
+    }
+    HIPCHK(hipMemsetAsync(c->slab, 0, n * sizeof(float), c->stream));
+    return 0;
+}
+
+extern "C" int nsk_grid_upload(nsk_ctx* c, int level, const float* h, int C, int Z, int Y, int X)
+{
+    if (!c || !h) return fail("nsk_grid_upload: null argument");
+    if (!which_ok(level)) return fail("nsk_grid_upload: bad level %d", level);
+    if (C != 32) return fail("nsk_grid_upload: C must be 32 (got %d)", C);
+    if (Z < 1 || Y < 1 || X < 1) return fail("nsk_grid_upload: bad shape");
+    HIPCHK(hipSetDevice(c->device));
+    GridState& G = c->grid[level];
+    size_t nvox = (size_t)Z * Y * X, n = nvox * 32;
+    bool realloc_ = n != G.n;
+    if (realloc_) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(G.v); hipFree(G.m); hipFree(G.s); hipFree(G.mask); G.mask = nullptr;
+        HIPCHK(hipMalloc(&G.v, n * 4)); HIPCHK(hipMalloc(&G.m, n * 4)); HIPCHK(hipMalloc(&G.s, n * 4));
+    }
+    if (G.Z != Z || G.Y != Y || G.X != X) { if (G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(G.mask); G.mask = nullptr; } }
+    G.C = C; G.Z = Z; G.Y = Y; G.X = X; G.n = n;
+    std::vector<float> t(n);
+    for (int ch = 0; ch < 32; ++ch)
+        for (size_t v = 0; v < nvox; ++v) t[v * 32 + ch] = h[(size_t)ch * nvox + v];
+    HIPCHK(hipMemcpyAsync(G.v, t.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(G.m, 0, n * 4, c->stream));
+    HIPCHK(hipMemsetAsync(G.s, 0, n * 4, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (realloc_) CHK(rebuild_slab(c));
+    return 0;
+}
+
+static int grid_fetch(nsk_ctx* c, int level, const float* src, float* h)
+{
+    GridState& G = c->grid[level];
+    if (!G.n) return fail("grid level %d not uploaded", level);
+    std::vector<float> t(G.n);
+    HIPCHK(hipMemcpyAsync(t.data(), src, G.n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    size_t nvox = G.n / 32;
+    for (int ch = 0; ch < 32; ++ch)
+        for (size_t v = 0; v < nvox; ++v) h[(size_t)ch * nvox + v] = t[v * 32 + ch];
+    return 0;
+}
+extern "C" int nsk_grid_download(nsk_ctx* c, int level, float* h)
+{
+    if (!c || !h || !which_ok(level)) return fail("nsk_grid_download: bad argument");
+    return grid_fetch(c, level, c->grid[level].v, h);
+}
+extern "C" int nsk_grid_grad_download(nsk_ctx* c, int level, float* h)
+{
+    if (!c || !h || !which_ok(level)) return fail("nsk_grid_grad_download: bad argument");
+    return grid_fetch(c, level, c->slab + c->grid[level].g_off, h);
+}
+
+extern "C" int nsk_set_mask(nsk_ctx* c, int level, const uint8_t* h_mask)
+{
+    if (!c || !which_ok(level)) return fail("nsk_set_mask: bad argument");
+    GridState& G = c->grid[level];
+    if (!G.n) return fail("nsk_set_mask: grid level %d not uploaded", level);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    size_t nvox = G.n / 32;
+    if (!h_mask) { if (G.mask) { hipFree(G.mask); G.mask = nullptr; } return 0; }
+    if (!G.mask) HIPCHK(hipMalloc(&G.mask, nvox));
+    HIPCHK(hipMemcpy(G.mask, h_mask, nvox, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ---- decoder images -------------------------------------------------------------------------------------
+static void seg_fwd(std::vector<int>& idx, int quad0, int KQ, int Wofs, int ld, int col0, int kvalid)
+{
+    for (int rt = 0; rt < 2; ++rt) for (int q = 0; q < KQ; ++q) for (int lane = 0; lane < 64; ++lane) for (int i = 0; i < 4; ++i) {
+        int o = 16 * rt + (lane & 15), k = 16 * q + 4 * (lane >> 4) + i;
+        idx[((size_t)(quad0 + rt * KQ + q) * 64 + lane) * 4 + i] = k < kvalid ? Wofs + o * ld + col0 + k : -1;
+    }
+}
+static void seg_bwd(std::vector<int>& idx, int quad0, int RT, int Wofs, int ld, int col0, int rvalid)
+{
+    const int KQ = 2;
+    for (int rt = 0; rt < RT; ++rt) for (int q = 0; q < KQ; ++q) for (int lane = 0; lane < 64; ++lane) for (int i = 0; i < 4; ++i) {
+        int r = 16 * rt + (lane & 15), k = 16 * q + 4 * (lane >> 4) + i;
+        idx[((size_t)(quad0 + rt * KQ + q) * 64 + lane) * 4 + i] = r < rvalid ? Wofs + k * ld + col0 + r : -1;
+    }
+}
+
+template <int CQ>
+static void build_mlp_fwd_idx(const DecLayout& L, std::vector<int>& idx)
+{
+    typedef MlpFwdImg<CQ> I;
+    idx.assign(I::TOTAL, -1);
+    seg_fwd(idx, I::W0E, 6, L.oW[0], NSK_E, 0, NSK_E);
+    for (int l = 0; l < 5; ++l) seg_fwd(idx, I::F(l), CQ, L.oFw[l], L.c_dim, 0, L.c_dim);
+    seg_fwd(idx, I::W1, 2, L.oW[1], 32, 0, 32);
+    seg_fwd(idx, I::W2, 2, L.oW[2], 32, 0, 32);
+    seg_fwd(idx, I::W3E, 6, L.oW[3], 125, 0, NSK_E);
+    seg_fwd(idx, I::W3H, 2, L.oW[3], 125, NSK_E, 32);
+    seg_fwd(idx, I::W4, 2, L.oW[4], 32, 0, 32);
+    for (int l = 0; l < 5; ++l) for (int o = 0; o < 32; ++o) { idx[I::P_B + 32 * l + o] = L.ob[l] + o; idx[I::P_BC + 32 * l + o] = L.oFb[l] + o; }
+    for (int o = 0; o < L.out_dim; ++o) { for (int k = 0; k < 32; ++k) idx[I::P_WO + 32 * o + k] = L.oWo + 32 * o + k; idx[I::P_BO + o] = L.obo + o; }
+    for (int a = 0; a < 3; ++a) for (int k = 0; k < NSK_E; ++k) idx[I::P_BM + 96 * a + k] = L.oB + NSK_E * a + k;
+}
+
+static void build_idx(int w, std::vector<int>& fidx, std::vector<int>& bidx)
+{
+    DecLayout L = nsk_dec_layout(w);
+    if (w == 0) {
+        typedef CoarseFwdImg I; typedef CoarseBwdImg J;
+        fidx.assign(I::TOTAL, -1); bidx.assign(J::TOTAL, -1);
+        seg_fwd(fidx, I::W0, 2, L.oW[0], 32, 0, 32); seg_fwd(fidx, I::W1, 2, L.oW[1], 32, 0, 32); seg_fwd(fidx, I::W2, 2, L.oW[2], 32, 0, 32);
+        seg_fwd(fidx, I::W3C, 2, L.oW[3], 64, 0, 32); seg_fwd(fidx, I::W3H, 2, L.oW[3], 64, 32, 32); seg_fwd(fidx, I::W4, 2, L.oW[4], 32, 0, 32);
+        for (int l = 0; l < 5; ++l) for (int o = 0; o < 32; ++o) fidx[I::P_B + 32 * l + o] = L.ob[l] + o;
+        for (int k = 0; k < 32; ++k) fidx[I::P_WO + k] = L.oWo + k;
+        fidx[I::P_BO] = L.obo;
+        seg_bwd(bidx, J::W0T, 2, L.oW[0], 32, 0, 32); seg_bwd(bidx, J::W1T, 2, L.oW[1], 32, 0, 32); seg_bwd(bidx, J::W2T, 2, L.oW[2], 32, 0, 32);
+        seg_bwd(bidx, J::W3CT, 2, L.oW[3], 64, 0, 32); seg_bwd(bidx, J::W3HT, 2, L.oW[3], 64, 32, 32); seg_bwd(bidx, J::W4T, 2, L.oW[4], 32, 0, 32);
+        for (int k = 0; k < 32; ++k) bidx[J::P_WO + k] = L.oWo + k;
+        return;
+    }
+    if (w == 2) build_mlp_fwd_idx<4>(L, fidx); else build_mlp_fwd_idx<2>(L, fidx);
+    typedef MlpBwdImg J;
+    bidx.assign(J::TOTAL, -1);
+    for (int l = 0; l < 5; ++l) seg_bwd(bidx, J::FT(l), 2, L.oFw[l], L.c_dim, 0, 32);
+    for (int l = 1; l < 5; ++l) seg_bwd(bidx, J::WT(l), 2, L.oW[l], L.in_dim[l], l == 3 ? NSK_E : 0, 32);
+    seg_bwd(bidx, J::W0ET, 6, L.oW[0], NSK_E, 0, NSK_E);
+    seg_bwd(bidx, J::W3ET, 6, L.oW[3], 125, 0, NSK_E);
+    for (int o = 0; o < L.out_dim; ++o) for (int k = 0; k < 32; ++k) bidx[J::P_WO + 32 * o + k] = L.oWo + 32 * o + k;
+    for (int a = 0; a < 3; ++a) for (int k = 0; k < NSK_E; ++k) bidx[J::P_BM + 96 * a + k] = L.oB + NSK_E * a + k;
+}
+
+static int repack(nsk_ctx* c, int w)
+{
+    DecState& D = c->dec[w];
+    k_pack<<<(D.fimg_n + 255) / 256, 256, 0, c->stream>>>(D.fimg, D.fidx, D.p, D.fimg_n);
+    k_pack<<<(D.bimg_n + 255) / 256, 256, 0, c->stream>>>(D.bimg, D.bidx, D.p, D.bimg_n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" size_t nsk_decoder_param_count(int which) { return which_ok(which) ? (size_t)nsk_dec_layout(which).total : 0; }
+
+extern "C" int nsk_decoder_upload(nsk_ctx* c, int w, const float* h, size_t n)
+{
+    if (!c || !h || !which_ok(w)) return fail("nsk_decoder_upload: bad argument");
+    if (n != nsk_decoder_param_count(w)) return fail("nsk_decoder_upload: decoder %d expects %zu parameters, got %zu", w, nsk_decoder_param_count(w), n);
+    HIPCHK(hipSetDevice(c->device));
+    DecState& D = c->dec[w];
+    if (!D.p) {
+        D.n = (int)n;
+        size_t n4 = (n + 3) & ~(size_t)3;
+        HIPCHK(hipMalloc(&D.p, n4 * 4)); HIPCHK(hipMalloc(&D.m, n4 * 4)); HIPCHK(hipMalloc(&D.s, n4 * 4));
+        HIPCHK(hipMemset(D.p, 0, n4 * 4));
+        std::vector<int> fi, bi;
+        build_idx(w, fi, bi);
+        D.fimg_n = (int)fi.size(); D.bimg_n = (int)bi.size();
+        HIPCHK(hipMalloc(&D.fimg, fi.size() * 4)); HIPCHK(hipMalloc(&D.bimg, bi.size() * 4));
+        HIPCHK(hipMalloc(&D.fidx, fi.size() * 4)); HIPCHK(hipMalloc(&D.bidx, bi.size() * 4));
+        HIPCHK(hipMemcpy(D.fidx, fi.data(), fi.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(D.bidx, bi.data(), bi.size() * 4, hipMemcpyHostToDevice));
+        CHK(rebuild_slab(c));
+    }
+    HIPCHK(hipMemcpyAsync(D.p, h, n * 4, hipMemcpyHostToDevice, c->stream));
+    size_t n4 = (n + 3) & ~(size_t)3;
+    HIPCHK(hipMemsetAsync(D.m, 0, n4 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(D.s, 0, n4 * 4, c->stream));
+    CHK(repack(c, w));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    D.loaded = true;
+    return 0;
+}
+
+static int dec_fetch(nsk_ctx* c, int w, const float* src, float* h, size_t n)
+{
+    if (!c->dec[w].loaded) return fail("decoder %d not uploaded", w);
+    if (n != (size_t)c->dec[w].n) return fail("decoder %d has %d parameters, buffer has %zu", w, c->dec[w].n, n);
+    HIPCHK(hipMemcpyAsync(h, src, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int nsk_decoder_download(nsk_ctx* c, int w, float* h, size_t n)
+{
+    if (!c || !h || !which_ok(w)) return fail("nsk_decoder_download: bad argument");
+    return dec_fetch(c, w, c->dec[w].p, h, n);
+}
+extern "C" int nsk_decoder_grad_download(nsk_ctx* c, int w, float* h, size_t n)
+{
+    if (!c || !h || !which_ok(w)) return fail("nsk_decoder_grad_download: bad argument");
+    return dec_fetch(c, w, c->slab + c->dec[w].g_off, h, n);
+}
+extern "C" int nsk_decoder_set_trainable(nsk_ctx* c, int w, int t)
+{
+    if (!c || !which_ok(w)) return fail("nsk_decoder_set_trainable: bad argument");
+    c->dec[w].trainable = t ? 1 : 0;
+    return 0;
+}
+
+// ---- workspace --------------------------------------------------------------------------------------------
+static int ensure_ws(nsk_ctx* c, int N, int M)
+{
+    Workspace& w = c->ws;
+    if (M <= w.capM && N <= w.capN) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int capM = std::max(M, w.capM), capN = std::max(N, w.capN);
+    free_ws(w);
+    size_t m = (size_t)capM + 64;
+    HIPCHK(hipMalloc(&w.z, m * 4));
+    for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&w.occ[i], m * 4));
+    HIPCHK(hipMalloc(&w.rgb4, m * 16));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipMalloc(&w.masks[i], m * 32));
+    HIPCHK(hipMalloc(&w.g_raw, m * 16));
+    size_t n = (size_t)capN + 64;
+    HIPCHK(hipMalloc(&w.ray_loss, n * 4));
+    HIPCHK(hipMalloc(&w.tmp_rgb, n * 12)); HIPCHK(hipMalloc(&w.tmp_depth, n * 4)); HIPCHK(hipMalloc(&w.tmp_var, n * 4));
+    w.capM = capM; w.capN = capN;
+    return 0;
+}
+
+static const int STAGE_DEC[4][3] = {{0, -1, -1}, {1, -1, -1}, {1, 2, -1}, {1, 2, 3}};
+
+static GridD grid_dev(nsk_ctx* c, int level, bool with_grad)
+{
+    GridD g;
+    GridState& G = c->grid[level];
+    g.v = G.v; g.g = with_grad ? c->slab + G.g_off : nullptr; g.mask = G.mask; g.Z = G.Z; g.Y = G.Y; g.X = G.X;
+    return g;
+}
+
+static int check_stage(nsk_ctx* c, int stage)
+{
+    if (stage < 0 || stage > 3) return fail("bad stage %d", stage);
+    for (int q = 0; q < 3; ++q) {
+        int w = STAGE_DEC[stage][q];
+        if (w < 0) break;
+        if (!c->grid[w].n) return fail("stage %d needs grid level %d (nsk_grid_upload)", stage, w);
+        if (!c->dec[w].loaded) return fail("stage %d needs decoder %d (nsk_decoder_upload)", stage, w);
+    }
+    return 0;
+}
+
+static void fill_args(nsk_ctx* c, DecArgs& A, int w, int M, int S, const float* ro, const float* rd, const float* pts)
+{
+    memset(&A, 0, sizeof(A));
+    A.rays_o = ro; A.rays_d = rd; A.z = c->ws.z; A.pts = pts; A.M = M; A.S = S;
+    memcpy(A.bound, c->R.bound, sizeof(A.bound));
+    A.grid = grid_dev(c, w, false);
+    if (w == 2) A.grid_mid = grid_dev(c, 1, false);
+    A.img = reinterpret_cast<const f4*>(c->dec[w].fimg);
+    A.bimg = reinterpret_cast<const f4*>(c->dec[w].bimg);
+    A.img_f4 = c->dec[w].fimg_n / 4;
+    A.out = w == 3 ? c->ws.rgb4 : c->ws.occ[w];
+}
+
+static int launch_decode_fwd(nsk_ctx* c, int w, int M, int S, const float* ro, const float* rd, const float* pts, bool save_masks)
+{
+    DecArgs A;
+    fill_args(c, A, w, M, S, ro, rd, pts);
+    A.masks = save_masks ? c->ws.masks[w] : nullptr;
+    int ntasks = (M + 15) / 16;
+    size_t lds = fwd_img_floats(w) * 4;
+    int maxwg = c->num_cu * (lds <= 80 * 1024 ? 2 : 1);
+    int grid = std::max(1, std::min((ntasks + 7) / 8, maxwg));
+    switch (w) {
+    case 0: k_decode_fwd<0><<<grid, 512, lds, c->stream>>>(A); break;
+    case 1: k_decode_fwd<1><<<grid, 512, lds, c->stream>>>(A); break;
+    case 2: k_decode_fwd<2><<<grid, 512, lds, c->stream>>>(A); break;
+    default: k_decode_fwd<3><<<grid, 512, lds, c->stream>>>(A); break;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, const float* rd, bool train, bool rays, unsigned flags,
+                             float* g_ro, float* g_rd)
+{
+    DecArgs A;
+    fill_args(c, A, w, M, S, ro, rd, nullptr);
+    A.grid = grid_dev(c, w, (flags & NSK_GRAD_GRIDS) != 0);
+    A.masks = c->ws.masks[w];
+    A.g_raw = c->ws.g_raw;
+    A.g_rays_o = g_ro; A.g_rays_d = g_rd;
+    A.g_dec = c->slab + c->dec[w].g_off;
+    A.flags = flags;
+    int ntasks = (M + 15) / 16;
+    size_t lds = bwd_lds_bytes(w, train);
+    int grid = std::max(1, std::min((ntasks + 7) / 8, c->num_cu));
+#define LB(W) \
+    if (train) { if (rays) k_decode_bwd<W, true, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd<W, true, false><<<grid, 512, lds, c->stream>>>(A); } \
+    else { if (rays) k_decode_bwd<W, false, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd<W, false, false><<<grid, 512, lds, c->stream>>>(A); }
+    switch (w) {
+    case 0: LB(0) break;
+    case 1: LB(1) break;
+    case 2: LB(2) break;
+    default: LB(3) break;
+    }
+#undef LB
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// algorithmic bytes / flops per sample
+static void account(nsk_ctx* c, int stage, int M, int N, bool bwd, unsigned flags)
+{
+    static const double fwd_b[4] = {1024, 1024, 2048, 3072}, fwd_f[4] = {12.4e3, 31.0e3, 72.2e3, 103.3e3};
+    double b = fwd_b[stage] + 5.0, f = fwd_f[stage];
+    if (bwd) {
+        int lv = stage == 0 ? 1 : stage;      // levels receiving gradient
+        if (flags & NSK_GRAD_GRIDS) b += 2048.0 * lv;
+        f *= 2.0;
+        if (flags & NSK_GRAD_DECODERS) for (int q = 0; q < 3; ++q) { int w = STAGE_DEC[stage][q]; if (w >= 0 && c->dec[w].trainable) f += 2.0 * (w == 0 ? 6176 : (w == 2 ? 20599 : 15500)); }
+    }
+    c->last_bytes = b * M; c->last_flops = f * M; c->last_samples = M; (void)N;
+}
+
+// sampling + decoders of the stage; leaves z / occ / rgb4 (and ReLU bits) in the workspace
+static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax, bool save_masks)
+{
+    const int M = N * S;
+    const float* gmax_dev = nullptr;
+    if (gt && gtmax < 0.f) {
+        k_depth_max<<<1, 1024, 0, c->stream>>>(N, gt, c->scal);
+        gmax_dev = c->scal;
+    }
+    k_sample<<<(N + 3) / 4, 256, 0, c->stream>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, c->ws.z);
+    HIPCHK(hipGetLastError());
+    for (int q = 0; q < 3; ++q) {
+        int w = STAGE_DEC[stage][q];
+        if (w < 0) break;
+        CHK(launch_decode_fwd(c, w, M, S, ro, rd, nullptr, save_masks));
+    }
+    return 0;
+}
+
+static void comp_args(nsk_ctx* c, CompArgs& A, int stage, int N, int S, const float* ro, const float* rd)
+{
+    memset(&A, 0, sizeof(A));
+    A.R = c->R; A.N = N; A.S = S; A.stage = stage; A.rays_o = ro; A.rays_d = rd; A.z = c->ws.z;
+    A.occ_a = stage == 0 ? c->ws.occ[0] : c->ws.occ[1];
+    A.occ_b = stage >= 2 ? c->ws.occ[2] : nullptr;
+    A.rgb4 = stage == 3 ? c->ws.rgb4 : nullptr;
+    A.g_raw = c->ws.g_raw;
+}
+
+static int common_checks(nsk_ctx* c, int stage, int N, const float* ro, const float* rd, int* S_out, const float* gt)
+{
+    if (!c) return fail("null ctx");
+    if (N < 1) return fail("N must be >= 1 (got %d)", N);
+    if (!ro || !rd) return fail("rays_o / rays_d is NULL");
+    CHK(check_stage(c, stage));
+    HIPCHK(hipSetDevice(c->device));
+    int S = c->R.n_samples + (gt ? c->R.n_surface : 0);
+    if ((long long)N * S > 0x7fffffffLL / 4) return fail("N*S too large");
+    CHK(ensure_ws(c, N, N * S));
+    *S_out = S;
+    return 0;
+}
+
+extern "C" int nsk_render_forward(nsk_ctx* c, int stage, int N, const float* ro, const float* rd, const float* gt, float gtmax,
+                                  float* rgb, float* depth, float* var, float* weights)
+{
+    int S;
+    CHK(common_checks(c, stage, N, ro, rd, &S, gt));
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, false));
+    CompArgs A;
+    comp_args(c, A, stage, N, S, ro, rd);
+    A.rgb = rgb; A.depth = depth; A.var = var; A.weights = weights; A.mode = 0;
+    k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    HIPCHK(hipGetLastError());
+    account(c, stage, N * S, N, false, 0);
+    return 0;
+}
+
+extern "C" int nsk_eval_points(nsk_ctx* c, int stage, int M, const float* pts, float* raw)
+{
+    if (!c || !pts || !raw) return fail("nsk_eval_points: null argument");
+    if (M < 1) return fail("nsk_eval_points: M must be >= 1");
+    CHK(check_stage(c, stage));
+    HIPCHK(hipSetDevice(c->device));
+    CHK(ensure_ws(c, 1, M));
+    for (int q = 0; q < 3; ++q) {
+        int w = STAGE_DEC[stage][q];
+        if (w < 0) break;
+        CHK(launch_decode_fwd(c, w, M, 1, nullptr, nullptr, pts, false));
+    }
+    k_eval_finish<<<(M + 255) / 256, 256, 0, c->stream>>>(M, stage, pts, c->d_bound, stage == 0 ? c->ws.occ[0] : c->ws.occ[1],
+                                                          stage >= 2 ? c->ws.occ[2] : nullptr, stage == 3 ? c->ws.rgb4 : nullptr, raw);
+    HIPCHK(hipGetLastError());
+    account(c, stage, M, 0, false, 0);
+    return 0;
+}
+
+// decoders' backward after k_composite wrote g_raw
+static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, unsigned flags, float* g_ro, float* g_rd)
+{
+    const bool rays = (flags & NSK_GRAD_RAYS) != 0;
+    for (int q = 2; q >= 0; --q) {
+        int w = STAGE_DEC[stage][q];
+        if (w < 0) continue;
+        bool train = (flags & NSK_GRAD_DECODERS) && c->dec[w].trainable;
+        bool grids = (flags & NSK_GRAD_GRIDS) != 0;
+        if (!train && !grids && !rays) continue;
+        CHK(launch_decode_bwd(c, w, N * S, S, ro, rd, train, rays, flags, g_ro, g_rd));
+        if (train) c->touched[NSK_GROUP_DECODERS] = true;
+        if (grids) c->touched[NSK_GROUP_COARSE + w] = true;
+    }
+    return 0;
+}
+
+extern "C" int nsk_render_backward(nsk_ctx* c, int stage, int N, const float* ro, const float* rd, const float* gt, float gtmax,
+                                   const float* g_rgb, const float* g_depth, const float* g_var, unsigned flags, float* g_ro, float* g_rd)
+{
+    int S;
+    CHK(common_checks(c, stage, N, ro, rd, &S, gt));
+    if (!g_rgb || !g_depth) return fail("nsk_render_backward: g_rgb / g_depth is NULL");
+    if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_render_backward: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true));
+    CompArgs A;
+    comp_args(c, A, stage, N, S, ro, rd);
+    A.mode = 1; A.g_rgb = g_rgb; A.g_depth = g_depth; A.g_var = g_var;
+    if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
+    k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    HIPCHK(hipGetLastError());
+    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
+    account(c, stage, N * S, N, true, flags);
+    return 0;
+}
+
+extern "C" int nsk_map_step(nsk_ctx* c, int stage, int N, const float* ro, const float* rd, const float* gt, const float* gtc,
+                            float gtmax, float w_color, int use_color, unsigned flags, float* d_loss, float* rgb, float* depth,
+                            float* var, float* g_ro, float* g_rd)
+{
+    int S;
+    if (!gt) return fail("nsk_map_step: gt_depth is NULL");
+    if (use_color && !gtc) return fail("nsk_map_step: use_color needs gt_color");
+    CHK(common_checks(c, stage, N, ro, rd, &S, gt));
+    if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_map_step: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true));
+    CompArgs A;
+    comp_args(c, A, stage, N, S, ro, rd);
+    A.mode = 2; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
+    A.rgb = rgb; A.depth = depth; A.var = var; A.loss = c->ws.ray_loss;
+    if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
+    k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    HIPCHK(hipGetLastError());
+    if (d_loss) k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss);
+    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
+    account(c, stage, N * S, N, true, flags);
+    return 0;
+}
+
+static int median_thr(nsk_ctx* c, int N, const float* gt, const float* depth)
+{
+    int P2 = 1; while (P2 < N) P2 <<= 1;
+    if (P2 > 16384) return fail("handle_dynamic median supports at most 16384 rays (got %d)", N);
+    k_median_thr<<<1, 1024, P2 * 4, c->stream>>>(N, P2, gt, depth, c->scal + 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nsk_track_step(nsk_ctx* c, int stage, int N, const float* ro, const float* rd, const float* gt, const float* gtc,
+                              float gtmax, float w_color, int use_color, int handle_dynamic, int detach_var, unsigned flags,
+                              float* d_loss, float* g_ro, float* g_rd)
+{
+    int S;
+    if (!gt) return fail("nsk_track_step: gt_depth is NULL");
+    if (use_color && !gtc) return fail("nsk_track_step: use_color needs gt_color");
+    CHK(common_checks(c, stage, N, ro, rd, &S, gt));
+    if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_track_step: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true));
+    CompArgs A;
+    comp_args(c, A, stage, N, S, ro, rd);
+    if (handle_dynamic) {                                      // forward pass for the median (Tracker.cpp:69-70)
+        A.mode = 0; A.depth = c->ws.tmp_depth;
+        k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+        CHK(median_thr(c, N, gt, c->ws.tmp_depth));
+        A.depth = nullptr;
+    }
+    A.mode = 3; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
+    A.thr = c->scal + 1; A.handle_dynamic = handle_dynamic; A.detach_var = detach_var; A.loss = c->ws.ray_loss;
+    if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
+    k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    HIPCHK(hipGetLastError());
+    if (d_loss) k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss);
+    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
+    account(c, stage, N * S, N, true, flags);
+    return 0;
+}
+
+extern "C" int nsk_loss_map(nsk_ctx* c, int N, const float* depth, const float* rgb, const float* gt, const float* gtc, float w_color,
+                            int use_color, float* g_depth, float* g_rgb, float* d_loss)
+{
+    if (!c || !depth || !rgb || !gt || !gtc || !g_depth || !g_rgb) return fail("nsk_loss_map: null argument");
+    if (N < 1) return fail("nsk_loss_map: N must be >= 1");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(ensure_ws(c, N, 1));
+    k_loss_map<<<(N + 255) / 256, 256, 0, c->stream>>>(N, depth, rgb, gt, gtc, w_color, use_color, g_depth, g_rgb, c->ws.ray_loss);
+    if (d_loss) k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nsk_loss_track(nsk_ctx* c, int N, const float* depth, const float* rgb, const float* var, const float* gt,
+                              const float* gtc, float w_color, int use_color, int handle_dynamic, int detach_var, float* g_depth,
+                              float* g_rgb, float* g_var, float* d_loss)
+{
+    if (!c || !depth || !rgb || !var || !gt || !gtc || !g_depth || !g_rgb) return fail("nsk_loss_track: null argument");
+    if (N < 1) return fail("nsk_loss_track: N must be >= 1");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(ensure_ws(c, N, 1));
+    if (handle_dynamic) CHK(median_thr(c, N, gt, depth));
+    k_loss_track<<<(N + 255) / 256, 256, 0, c->stream>>>(N, depth, rgb, var, gt, gtc, w_color, use_color, handle_dynamic, detach_var,
+                                                         c->scal + 1, g_depth, g_rgb, g_var, c->ws.ray_loss);
+    if (d_loss) k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- rays / pose --------------------------------------------------------------------------------------------
+static void intr(int mode, float& fx, float& fy, float& cx, float& cy)
+{
+    if (mode & 2) { fx = (float)(int)fx; fy = (float)(int)fy; cx = (float)(int)cx; cy = (float)(int)cy; }   // D10
+}
+extern "C" int nsk_rays_from_pixels(nsk_ctx* c, int n, const int32_t* pi, const int32_t* pj, float fx, float fy, float cx, float cy,
+                                    const float* c2w, int mode, float* ro, float* rd)
+{
+    if (!c || !pi || !pj || !c2w || !ro || !rd || n < 1) return fail("nsk_rays_from_pixels: bad argument");
+    intr(mode, fx, fy, cx, cy);
+    k_rays_from_pixels<<<(n + 255) / 256, 256, 0, c->stream>>>(n, pi, pj, fx, fy, cx, cy, c2w, mode, ro, rd);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int nsk_rays_backward(nsk_ctx* c, int n, const int32_t* pi, const int32_t* pj, float fx, float fy, float cx, float cy, int mode,
+                                 const float* g_ro, const float* g_rd, float* g_c2w)
+{
+    if (!c || !pi || !pj || !g_ro || !g_rd || !g_c2w || n < 1) return fail("nsk_rays_backward: bad argument");
+    intr(mode, fx, fy, cx, cy);
+    k_rays_backward<<<1, 256, 0, c->stream>>>(n, pi, pj, fx, fy, cx, cy, mode, g_ro, g_rd, g_c2w);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int nsk_camera_from_tensor(nsk_ctx* c, const float* cam, float* c2w)
+{
+    if (!c || !cam || !c2w) return fail("nsk_camera_from_tensor: null argument");
+    k_camera_from_tensor<<<1, 1, 0, c->stream>>>(cam, c2w);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int nsk_camera_backward(nsk_ctx* c, const float* cam, const float* g_c2w, float* g_cam)
+{
+    if (!c || !cam || !g_c2w || !g_cam) return fail("nsk_camera_backward: null argument");
+    k_camera_backward<<<1, 1, 0, c->stream>>>(cam, g_c2w, g_cam);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int nsk_inside_filter(nsk_ctx* c, int N, const float* ro, const float* rd, const float* gt, uint8_t* keep)
+{
+    if (!c || !ro || !rd || !gt || !keep || N < 1) return fail("nsk_inside_filter: bad argument");
+    k_inside_filter<<<(N + 255) / 256, 256, 0, c->stream>>>(c->R, N, ro, rd, gt, keep);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static void adam_consts(float lr, float b1, float b2, int step, float& step_size, float& bc2s)
+{
+    float bc1 = 1.f - (float)pow((double)b1, step);
+    float bc2 = 1.f - (float)pow((double)b2, step);
+    step_size = lr / bc1; bc2s = sqrtf(bc2);
+}
+
+extern "C" int nsk_adam_vector(nsk_ctx* c, int n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, int step)
+{
+    if (!c || !p || !g || !m || !v || n < 1 || step < 1) return fail("nsk_adam_vector: bad argument");
+    float ss, bc2s; adam_consts(lr, b1, b2, step, ss, bc2s);
+    k_adam_scalar<<<(n + 255) / 256, 256, 0, c->stream>>>(n, p, g, m, v, ss, bc2s, b1, b2, eps);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- optimiser ------------------------------------------------------------------------------------------------
+extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b1, float b2, float eps)
+{
+    if (!c || !lr) return fail("nsk_adam_step: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    for (int lv = 0; lv < 4; ++lv) {
+        int grp = NSK_GROUP_COARSE + lv;
+        if (!c->touched[grp] || !c->grid[lv].n) continue;
+        int step = ++c->adam_step[grp];
+        float ss, bc2s; adam_consts(lr[grp], b1, b2, step, ss, bc2s);
+        GridState& G = c->grid[lv];
+        int n = (int)G.n;
+        k_adam<<<(n / 4 + 255) / 256, 256, 0, c->stream>>>(n, G.v, c->slab + G.g_off, G.m, G.s, G.mask, ss, bc2s, b1, b2, eps);
+        c->touched[grp] = false;
+    }
+    if (c->touched[NSK_GROUP_DECODERS]) {
+        int step = ++c->adam_step[NSK_GROUP_DECODERS];
+        float ss, bc2s; adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, ss, bc2s);
+        for (int w = 0; w < 4; ++w) {
+            DecState& D = c->dec[w];
+            if (!D.trainable || !D.loaded) continue;
+            int n4 = (D.n + 3) & ~3;
+            k_adam<<<(n4 / 4 + 255) / 256, 256, 0, c->stream>>>(n4, D.p, c->slab + D.g_off, D.m, D.s, nullptr, ss, bc2s, b1, b2, eps);
+            CHK(repack(c, w));
+        }
+        c->touched[NSK_GROUP_DECODERS] = false;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nsk_adam_reset(nsk_ctx* c)
+{
+    if (!c) return fail("null ctx");
+    for (int i = 0; i < 4; ++i) {
+        if (c->grid[i].n) { HIPCHK(hipMemsetAsync(c->grid[i].m, 0, c->grid[i].n * 4, c->stream)); HIPCHK(hipMemsetAsync(c->grid[i].s, 0, c->grid[i].n * 4, c->stream)); }
+        if (c->dec[i].p) { size_t n4 = (c->dec[i].n + 3) & ~3; HIPCHK(hipMemsetAsync(c->dec[i].m, 0, n4 * 4, c->stream)); HIPCHK(hipMemsetAsync(c->dec[i].s, 0, n4 * 4, c->stream)); }
+    }
+    for (int g = 0; g < NSK_NUM_GROUPS; ++g) { c->adam_step[g] = 0; c->touched[g] = false; }
+    return 0;
+}
+
+extern "C" int nsk_zero_grads(nsk_ctx* c)
+{
+    if (!c) return fail("null ctx");
+    if (c->slab) HIPCHK(hipMemsetAsync(c->slab, 0, c->slab_n * 4, c->stream));
+    for (int g = 0; g < NSK_NUM_GROUPS; ++g) c->touched[g] = false;
+    return 0;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------------------
+extern "C" int nsk_grad_slab(nsk_ctx* c, float** p, size_t* n)
+{
+    if (!c || !p || !n) return fail("nsk_grad_slab: null argument");
+    *p = c->slab; *n = c->slab_n;
+    return 0;
+}
+
+extern "C" int nsk_allreduce_grads(nsk_ctx* c, void* comm)
+{
+    if (!c || !comm) return fail("nsk_allreduce_grads: null argument");
+    typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_t fn = nullptr;
+    if (!fn) {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return fail("nsk_allreduce_grads: cannot load librccl.so: %s", dlerror());
+        fn = (allreduce_t)dlsym(h, "ncclAllReduce");
+        if (!fn) return fail("nsk_allreduce_grads: ncclAllReduce not found");
+    }
+    const int ncclFloat32 = 7, ncclSum = 0;
+    int r = fn(c->slab, c->slab, c->slab_n, ncclFloat32, ncclSum, comm, c->stream);
+    if (r != 0) return fail("ncclAllReduce failed with %d", r);
+    return 0;
+}
+
+extern "C" int nsk_last_call_stats(nsk_ctx* c, double* b, double* f, int* s)
+{
+    if (!c) return fail("null ctx");
+    if (b) *b = c->last_bytes; if (f) *f = c->last_flops; if (s) *s = c->last_samples;
+    return 0;
+}

@@ -1,0 +1,986 @@
+// nsk_device.h -- gfx950 device code of the render / map / track kernel family.
+// Wave = 64 lanes; MFMA = v_mfma_f32_16x16x4_f32 (exact fp32, SURVEY.md 7.2: the 1e-4 contract needs fp32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nsk_layout.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct RParams {            // Renderer constants, reference src/Renderer.cpp:5-15
+    float bound[6];
+    int n_samples, n_surface, lindisp, occupancy;
+    float perturb;
+    unsigned long long seed;
+};
+
+struct GridD {              // one feature grid level, voxel-major [Z][Y][X][32]
+    const float* v;
+    float* g;               // gradient (same layout) or nullptr
+    const uint8_t* mask;    // per-voxel optimiser mask or nullptr
+    int Z, Y, X;
+};
+
+#define NSK_INF __builtin_huge_valf()
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// ------------------------------------------------------------------------------------------------------
+// exact-sequence scalar helpers: the sampling geometry feeds sin(25*x) and ReLU kinks, so it is evaluated
+// with the same rounding sequence as the reference's libtorch ops (separate mul / add, no FMA contraction)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+
+// at::linspace CPU kernel (reference src/Renderer.cpp:86,101)
+__device__ __forceinline__ float linspace01(int i, int steps)
+{
+    if (steps == 1) return 0.f;
+    float step = div_rn(1.f, (float)(steps - 1));
+    return i < steps / 2 ? mul_rn(step, (float)i) : sub_rn(1.f, mul_rn(step, (float)(steps - 1 - i)));
+}
+
+// reference src/Renderer.cpp:66-73, src/Mapper.cpp:417-421: min_axis max_side (bound - o)/d
+__device__ __forceinline__ float ray_box_far(const float* bound, float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    float o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+    float far = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t0 = div_rn(sub_rn(bound[2 * k], o[k]), d[k]);
+        float t1 = div_rn(sub_rn(bound[2 * k + 1], o[k]), d[k]);
+        float m = t0 > t1 ? t0 : t1;
+        if (k == 0 || m < far) far = m;
+    }
+    return far;
+}
+
+__device__ __forceinline__ uint32_t hash_u32(unsigned long long seed, uint32_t a, uint32_t b)
+{
+    unsigned long long x = seed ^ (0x9E3779B97F4A7C15ull * ((unsigned long long)a + 1)) ^
+                           (0xC2B2AE3D27D4EB4Full * ((unsigned long long)b + 1));
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+    return (uint32_t)(x >> 32);
+}
+
+// wave-wide helpers (64 lanes)
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K0: batch maximum of gt_depth (reference src/Renderer.cpp:76,93 torch::max(gt_depth)) -> *out
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_depth_max(int N, const float* __restrict__ gt, float* __restrict__ out)
+{
+    __shared__ float sh[16];
+    float m = -NSK_INF;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) m = fmaxf(m, gt[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, sh[w]);
+        *out = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K1: per-ray z sampling (reference src/Renderer.cpp:44-119).  One wave per ray, lane = sample slot.
+// z_out [N][S] sorted ascending.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample(RParams R, int N, int S, const float* __restrict__ rays_o,
+                                                const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+                                                float gtmax_host, const float* __restrict__ gtmax_dev,
+                                                float* __restrict__ z_out)
+{
+    __shared__ float sh[4][64];
+    __shared__ float sh2[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;                                 // whole wave exits together
+    const bool has_gt = gt_depth != nullptr;
+    const int ns = R.n_samples;
+    const int nsurf = S - ns;
+    const float gt = has_gt ? gt_depth[n] : 0.f;
+    const float gmax = gtmax_dev ? *gtmax_dev : gtmax_host;
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    float near = has_gt ? mul_rn(gt, 0.01f) : 0.01f;                        // :57,:63
+    float far = add_rn(ray_box_far(R.bound, ox, oy, oz, dx, dy, dz), 0.01f);   // :69-73
+    if (has_gt) {                                                           // :76
+        float hi = mul_rn(gmax, 1.2f);
+        if (far < 0.f) far = 0.f;
+        if (far > hi) far = hi;
+    }
+    float z = NSK_INF;
+    if (lane < ns) {                                                        // :101-108
+        float t = linspace01(lane, ns);
+        if (!R.lindisp) z = add_rn(mul_rn(near, sub_rn(1.f, t)), mul_rn(far, t));
+        else z = div_rn(1.f, add_rn(mul_rn(div_rn(1.f, near), sub_rn(1.f, t)), mul_rn(div_rn(1.f, far), t)));
+    }
+    if (R.perturb > 0.f) {                                                  // :110-117
+        sh[wave][lane] = z;
+        lds_fence();
+        if (lane < ns) {
+            float zl = lane > 0 ? sh[wave][lane - 1] : z;
+            float zu = lane < ns - 1 ? sh[wave][lane + 1] : z;
+            float lo = lane == 0 ? z : mul_rn(0.5f, add_rn(z, zl));
+            float up = lane == ns - 1 ? z : mul_rn(0.5f, add_rn(zu, z));
+            float u = (float)(hash_u32(R.seed, (uint32_t)n, (uint32_t)lane) >> 8) * (1.0f / 16777216.0f);
+            z = add_rn(lo, mul_rn(sub_rn(up, lo), u));
+        }
+        lds_fence();
+    }
+    if (lane >= ns && lane < S) {                                           // :80-99
+        float t = linspace01(lane - ns, nsurf);
+        if (gt > 0.f) z = add_rn(mul_rn(mul_rn(0.95f, gt), sub_rn(1.f, t)), mul_rn(mul_rn(1.05f, gt), t));
+        else z = add_rn(mul_rn(0.001f, sub_rn(1.f, t)), mul_rn(gmax, t));
+    }
+    if (nsurf > 0) {                                                        // :119 sort(cat) as a rank sort
+        sh[wave][lane] = z;
+        lds_fence();
+        int rank = 0;
+        for (int k = 0; k < S; ++k) {
+            float zk = sh[wave][k];
+            rank += (zk < z || (zk == z && k < lane)) ? 1 : 0;
+        }
+        if (lane < S) sh2[wave][rank] = z;
+        lds_fence();
+        z = sh2[wave][lane];
+    }
+    if (lane < S) z_out[(size_t)n * S + lane] = z;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// trilinear lookup = F::grid_sample(bilinear, border, align_corners=true) (reference src/models/MLP.cpp:51-63,
+// normalize_3d_coordinate include/torchlib/utils.h:132-139; ATen GridSampler.h:27-83)
+// ------------------------------------------------------------------------------------------------------
+struct Tri {
+    int vox[8];      // voxel index of corner c = dz*4 + dy*2 + dx (clamped into the grid)
+    float w[8];      // trilinear weight (0 for corners outside the grid)
+    float t[3];      // fractional coordinates
+    float gmul[3];   // d(index)/d(world), 0 where the coordinate was clipped
+};
+
+__device__ __forceinline__ void tri_setup(const GridD& G, const float* bound, float px, float py, float pz, Tri& T)
+{
+    const int dims[3] = {G.X, G.Y, G.Z};
+    const float p[3] = {px, py, pz};
+    int i0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float lo = bound[2 * k], hi = bound[2 * k + 1];
+        float u = sub_rn(mul_rn(div_rn(sub_rn(p[k], lo), sub_rn(hi, lo)), 2.f), 1.f);
+        float x = mul_rn(div_rn(add_rn(u, 1.f), 2.f), (float)(dims[k] - 1));
+        float mul = mul_rn(div_rn((float)(dims[k] - 1), 2.f), div_rn(2.f, sub_rn(hi, lo)));
+        float mx = (float)(dims[k] - 1);
+        if (x <= 0.f) { x = 0.f; mul = 0.f; }
+        else if (x >= mx) { x = mx; mul = 0.f; }
+        float f = floorf(x);
+        i0[k] = max(0, min((int)f, dims[k] - 1));     // NaN / inf coordinates stay inside the grid
+        T.t[k] = sub_rn(x, f); T.gmul[k] = mul;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+        int ix = i0[0] + dx, iy = i0[1] + dy, iz = i0[2] + dz;
+        bool in = ix < G.X && iy < G.Y && iz < G.Z;
+        float w = mul_rn(mul_rn(dx ? T.t[0] : sub_rn(1.f, T.t[0]), dy ? T.t[1] : sub_rn(1.f, T.t[1])),
+                         dz ? T.t[2] : sub_rn(1.f, T.t[2]));
+        ix = min(ix, G.X - 1); iy = min(iy, G.Y - 1); iz = min(iz, G.Z - 1);
+        T.vox[c] = (iz * G.Y + iy) * G.X + ix;
+        T.w[c] = in ? w : 0.f;
+    }
+}
+
+// gather the 8 channels {4g..4g+3, 16+4g..16+4g+3} of this lane's quarter into two D-layout quads
+__device__ __forceinline__ void tri_gather(const GridD& G, const Tri& T, int g, f4& c0, f4& c1)
+{
+    c0 = (f4)(0.f); c1 = (f4)(0.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f4* vp = reinterpret_cast<const f4*>(G.v + (size_t)T.vox[c] * 32 + 4 * g);
+        f4 a = vp[0], b = vp[4];
+        c0 += T.w[c] * a; c1 += T.w[c] * b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// A-fragment GEMM: acc[rt] += W[16rt.., :] x  for an input of KQ quads (D layout) -- see nsk_layout.h
+// ------------------------------------------------------------------------------------------------------
+template <int RT, int KQ>
+__device__ __forceinline__ void gemm(const f4* __restrict__ img, int quad0, int lane, const f4 (&x)[KQ], f4 (&acc)[RT])
+{
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        f4 a[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a[r] = img[(quad0 + r * KQ + q) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = mfma4(a[r][i], x[q][i], acc[r]);
+    }
+}
+
+// bias vector [32] in D layout: lane holds features 4g+i and 16+4g+i
+__device__ __forceinline__ void load_bias(const float* __restrict__ b, int g, f4 (&acc)[2])
+{
+    acc[0] = *reinterpret_cast<const f4*>(b + 4 * g);
+    acc[1] = *reinterpret_cast<const f4*>(b + 16 + 4 * g);
+}
+
+// ReLU in place, returns the 8 sign bits (bit r*4+i)
+__device__ __forceinline__ uint32_t relu_mask(f4 (&a)[2])
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (a[r][i] > 0.f) m |= 1u << (r * 4 + i);
+            else a[r][i] = 0.f;
+        }
+    return m;
+}
+
+template <int CQ>
+struct Act {               // activations of one 16-sample tile, D layout
+    f4 xe[6];              // sin(pB), k = 16q+4g+i (k>=93: 0)
+    f4 xc[CQ];             // grid features (fine: quads 2,3 = grid_middle features)
+    f4 h[5][2];            // block outputs
+    unsigned long long mask;   // ReLU bits, layer l -> bits 8l..8l+7
+};
+
+// sin / cos with a 3-term Cody-Waite reduction by pi/2 using FMA (each product is exact inside the FMA) and
+// minimax polynomials on [-pi/4, pi/4]: ~1 ulp for |x| < 1e5 (arguments here are |p| * 25 * N(0,1) ~ 1e2).
+// The library sinf carries a Payne-Hanek path that costs ~100 VALU instructions per call.
+__device__ __forceinline__ void nsk_sincos(float x, float& sn, float& cs)
+{
+    const float k = rintf(x * 0.636619747f);                 // 2/pi
+    float r = fmaf(k, -1.57079625129699707031f, x);          // pi/2 split: 0x1.921fb4p+0
+    r = fmaf(k, -7.54978941586159635335e-08f, r);            //             0x1.4442d0p-24
+    r = fmaf(k, -5.39030252995776476e-15f, r);               //             0x1.846988p-48
+    const float r2 = r * r;
+    float ps = fmaf(r2, 2.60831598e-6f, -1.98106880e-4f);    // sin(r) = r + r^3 * P(r^2)
+    ps = fmaf(ps, r2, 8.33307430e-3f);
+    ps = fmaf(ps, r2, -1.66666597e-1f);
+    const float s = fmaf(ps * r2, r, r);
+    float pc = fmaf(r2, 2.44331571e-5f, -1.38873163e-3f);    // cos(r) = 1 - r^2/2 + r^4 * Q(r^2)
+    pc = fmaf(pc, r2, 4.16666457e-2f);
+    const float c = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float s1 = (q & 1) ? c : s;
+    const float c1 = (q & 1) ? s : c;
+    sn = (q & 2) ? -s1 : s1;
+    cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// embedding e = sin(p B) (reference src/models/GaussianFFT.cpp:10-15), optional cos for the backward
+template <bool WANT_COS>
+__device__ __forceinline__ void embed(const float* __restrict__ Bm /*[3][96]*/, int g, float px, float py, float pz,
+                                      f4 (&xe)[6], f4 (&xcos)[6])
+{
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        f4 b0 = *reinterpret_cast<const f4*>(Bm + 16 * q + 4 * g);
+        f4 b1 = *reinterpret_cast<const f4*>(Bm + 96 + 16 * q + 4 * g);
+        f4 b2 = *reinterpret_cast<const f4*>(Bm + 192 + 16 * q + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int k = 16 * q + 4 * g + i;
+            float s = add_rn(add_rn(mul_rn(px, b0[i]), mul_rn(py, b1[i])), mul_rn(pz, b2[i]));
+            float sv, cv;
+            nsk_sincos(s, sv, cv);
+            xe[q][i] = k < NSK_E ? sv : 0.f;
+            xcos[q][i] = (WANT_COS && k < NSK_E) ? cv : 0.f;
+        }
+    }
+}
+
+// MLP::forward (reference src/models/MLP.cpp:76-102, intended loop D14): fills A.h and A.mask
+template <int CQ>
+__device__ __forceinline__ void mlp_forward(const f4* __restrict__ img, int lane, Act<CQ>& A)
+{
+    typedef MlpFwdImg<CQ> I;
+    const float* imgf = reinterpret_cast<const float*>(img);
+    const int g = lane >> 4;
+    unsigned long long mask = 0;
+    f4 acc[2];
+    // block 0
+    load_bias(imgf + I::P_B, g, acc);
+    gemm<2, 6>(img, I::W0E, lane, A.xe, acc);
+    mask |= (unsigned long long)relu_mask(acc);
+    { f4 bc[2]; load_bias(imgf + I::P_BC, g, bc); acc[0] += bc[0]; acc[1] += bc[1]; }
+    gemm<2, CQ>(img, I::F0, lane, A.xc, acc);
+    A.h[0][0] = acc[0]; A.h[0][1] = acc[1];
+#pragma unroll
+    for (int l = 1; l < 5; ++l) {
+        load_bias(imgf + I::P_B + 32 * l, g, acc);
+        if (l == 3) {
+            gemm<2, 6>(img, I::W3E, lane, A.xe, acc);
+            gemm<2, 2>(img, I::W3H, lane, A.h[2], acc);
+        } else {
+            gemm<2, 2>(img, I::W(l), lane, A.h[l - 1], acc);
+        }
+        mask |= (unsigned long long)relu_mask(acc) << (8 * l);
+        { f4 bc[2]; load_bias(imgf + I::P_BC + 32 * l, g, bc); acc[0] += bc[0]; acc[1] += bc[1]; }
+        gemm<2, CQ>(img, I::F(l), lane, A.xc, acc);
+        A.h[l][0] = acc[0]; A.h[l][1] = acc[1];
+    }
+    A.mask = mask;
+}
+
+// output_linear (32 -> OD) as a wave dot product: partial over this lane's 8 features, summed over g
+template <int OD>
+__device__ __forceinline__ void mlp_output(const float* __restrict__ Wo, const float* __restrict__ bo, int g,
+                                           const f4 (&h4)[2], float (&out)[OD])
+{
+#pragma unroll
+    for (int o = 0; o < OD; ++o) {
+        f4 w0 = *reinterpret_cast<const f4*>(Wo + 32 * o + 4 * g);
+        f4 w1 = *reinterpret_cast<const f4*>(Wo + 32 * o + 16 + 4 * g);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += w0[i] * h4[0][i] + w1[i] * h4[1][i];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        out[o] = s + bo[o];
+    }
+}
+
+// MLP_no_xyz::forward (reference src/models/MLP.cpp:165-182, intended loop D15)
+struct ActC { f4 xc[2]; f4 h[5][2]; unsigned long long mask; };
+__device__ __forceinline__ void coarse_forward(const f4* __restrict__ img, int lane, ActC& A)
+{
+    typedef CoarseFwdImg I;
+    const float* imgf = reinterpret_cast<const float*>(img);
+    const int g = lane >> 4;
+    unsigned long long mask = 0;
+    f4 acc[2];
+    const int Wq[5] = {I::W0, I::W1, I::W2, I::W3H, I::W4};
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        load_bias(imgf + I::P_B + 32 * l, g, acc);
+        if (l == 0) gemm<2, 2>(img, I::W0, lane, A.xc, acc);
+        else {
+            if (l == 3) gemm<2, 2>(img, I::W3C, lane, A.xc, acc);
+            gemm<2, 2>(img, Wq[l], lane, A.h[l - 1], acc);
+        }
+        mask |= (unsigned long long)relu_mask(acc) << (8 * l);
+        A.h[l][0] = acc[0]; A.h[l][1] = acc[1];
+    }
+    A.mask = mask;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2: decoder forward over flat 16-sample tiles.  Persistent workgroups of 8 waves; the decoder's forward
+// image lives in LDS for the lifetime of the workgroup.  WHICH: 0 coarse, 1 middle, 2 fine, 3 color.
+// Sample m = ray (m / S), slot (m % S): p = o + d z[m]; or, when pts != nullptr, p = pts[m] (eval_points).
+// ------------------------------------------------------------------------------------------------------
+struct DecArgs {
+    const float* rays_o; const float* rays_d; const float* z; const float* pts;
+    int M, S;
+    float bound[6];
+    GridD grid, grid_mid;
+    const f4* img;            // forward image (global)
+    const f4* bimg;           // backward image (global)
+    int img_f4;               // forward image size in f4
+    float* out;               // occupancy [M] (which<3) or rgb4 [M][4] (color)
+    unsigned long long* masks;   // [M][4] ReLU bits or nullptr
+    // backward only
+    const float* g_raw;       // [M][4] = (g_rgb[3], g_sigma)
+    float* g_rays_o; float* g_rays_d;    // [N][3] accumulated with atomics, or nullptr
+    float* g_dec;             // canonical decoder gradient (trainable) or nullptr
+    unsigned flags;
+};
+
+__device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px, float& py, float& pz, float& zz, int& n)
+{
+    if (A.pts) { px = A.pts[3 * mm]; py = A.pts[3 * mm + 1]; pz = A.pts[3 * mm + 2]; zz = 0.f; n = 0; return; }
+    n = mm / A.S;
+    zz = A.z[mm];
+    px = add_rn(A.rays_o[3 * n], mul_rn(A.rays_d[3 * n], zz));           // reference src/Renderer.cpp:121
+    py = add_rn(A.rays_o[3 * n + 1], mul_rn(A.rays_d[3 * n + 1], zz));
+    pz = add_rn(A.rays_o[3 * n + 2], mul_rn(A.rays_d[3 * n + 2], zz));
+}
+
+template <int WHICH>
+__global__ __launch_bounds__(512) void k_decode_fwd(DecArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) f4 smem[];
+    for (int i = threadIdx.x; i < A.img_f4; i += 512) smem[i] = A.img[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const float* imgf = reinterpret_cast<const float*>(smem);
+    const int ntasks = (A.M + 15) >> 4;
+    for (int task = blockIdx.x * 8 + wave; task < ntasks; task += gridDim.x * 8) {
+        asm volatile("" ::: "memory");      // keep the LDS fragment reads inside the loop (LICM would hoist + spill them)
+        const int m = task * 16 + j;
+        const int mm = min(m, A.M - 1);
+        float px, py, pz, zz; int n;
+        sample_point(A, mm, px, py, pz, zz, n);
+        Tri T;
+        tri_setup(A.grid, A.bound, px, py, pz, T);
+        if constexpr (WHICH == 0) {
+            ActC C;
+            tri_gather(A.grid, T, g, C.xc[0], C.xc[1]);
+            coarse_forward(smem, lane, C);
+            float out[1];
+            mlp_output<1>(imgf + CoarseFwdImg::P_WO, imgf + CoarseFwdImg::P_BO, g, C.h[4], out);
+            if (m < A.M) {
+                if (g == 0) A.out[m] = out[0];
+                if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
+            }
+        } else {
+            constexpr int CQ = WHICH == 2 ? 4 : 2;
+            constexpr int OD = WHICH == 3 ? 4 : 1;
+            typedef MlpFwdImg<CQ> I;
+            Act<CQ> C;
+            tri_gather(A.grid, T, g, C.xc[0], C.xc[1]);
+            if constexpr (WHICH == 2) {                     // reference MLP.cpp:79-84 concat_feat
+                Tri Tm;
+                tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
+                tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
+            }
+            f4 dummy[6];
+            embed<false>(imgf + I::P_BM, g, px, py, pz, C.xe, dummy);
+            mlp_forward<CQ>(smem, lane, C);
+            float out[OD];
+            mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);
+            if (m < A.M) {
+                if (g == 0) {
+                    if constexpr (OD == 4) *reinterpret_cast<f4*>(A.out + (size_t)m * 4) = (f4){out[0], out[1], out[2], out[OD - 1]};
+                    else A.out[m] = out[0];
+                }
+                if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3: compositing (reference include/torchlib/utils.h:148-172) + in-bound override (src/Renderer.cpp:26-36).
+// One wave per ray, lane = sample.  mode 0: forward only.
+// Backward modes produce g_raw [M][4] = (w*g_rgb, g_sigma) (g_sigma = 0 for out-of-bound samples) and the
+// seed of g_rays_d from the |d| term:  1 = upstream arrays, 2 = Mapper loss, 3 = Tracker loss.
+// ------------------------------------------------------------------------------------------------------
+struct CompArgs {
+    RParams R;
+    int N, S, stage;
+    const float* rays_o; const float* rays_d; const float* z;
+    const float* occ_a; const float* occ_b;     // occupancy parts: stage0 coarse | 1 middle | 2,3 middle + fine
+    const float* rgb4;                          // color decoder output [M][4] (stage 3) or nullptr
+    float* rgb; float* depth; float* var; float* weights;      // forward outputs (may be nullptr)
+    int mode;
+    const float* g_rgb; const float* g_depth; const float* g_var;            // mode 1
+    const float* gt_depth; const float* gt_color; float w_color; int use_color;   // modes 2,3
+    const float* thr; int handle_dynamic; int detach_var;                     // mode 3 (thr: device scalar)
+    float* loss;                                                              // modes 2,3: per-ray loss [N] or nullptr
+    float* g_raw;                                                             // [M][4]
+    float* g_rays_o; float* g_rays_d;                                         // [N][3] seeds or nullptr
+};
+
+__device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void k_composite(CompArgs A)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= A.N) return;
+    const int S = A.S;
+    const bool act = lane < S;
+    const size_t m = (size_t)n * S + (act ? lane : S - 1);
+    const float ox = A.rays_o[3 * n], oy = A.rays_o[3 * n + 1], oz = A.rays_o[3 * n + 2];
+    const float dx = A.rays_d[3 * n], dy = A.rays_d[3 * n + 1], dz = A.rays_d[3 * n + 2];
+    const float z = A.z[m];
+    const float px = add_rn(ox, mul_rn(dx, z)), py = add_rn(oy, mul_rn(dy, z)), pz = add_rn(oz, mul_rn(dz, z));
+    const float* b = A.R.bound;
+    const bool inb = px < b[1] && px > b[0] && py < b[3] && py > b[2] && pz < b[5] && pz > b[4];
+    float occ = A.occ_a[m];
+    if (A.occ_b) occ = A.occ_b[m] + occ;                       // fine_occ + middle_occ (NICE.cpp:40,49)
+    const float sg = inb ? occ : 100.f;                        // Renderer.cpp:36
+    f4 col = (f4)(0.f);
+    if (A.rgb4) col = *reinterpret_cast<const f4*>(A.rgb4 + m * 4);
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    float znext = __shfl_down(z, 1);
+    const float dzv = (lane + 1 < S) ? (znext - z) : 1e10f;
+    const float dist = dzv * nrm;
+    float alpha, ex = 0.f;
+    if (A.R.occupancy) alpha = 1.f / (1.f + expf(-10.f * sg));
+    else { ex = expf(-fmaxf(sg, 0.f) * dist); alpha = 1.f - ex; }
+    if (!act) alpha = 0.f;
+    // T = exclusive prefix product of (1 - alpha + 1e-10)
+    float fct = act ? (1.f - alpha + 1e-10f) : 1.f;
+    float incl = fct;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float up = __shfl_up(incl, o);
+        if (lane >= o) incl *= up;
+    }
+    float T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.f;
+    const float w = act ? alpha * T : 0.f;
+    const float D = wave_sum(w * z);
+    const float cr = wave_sum(w * col[0]), cg = wave_sum(w * col[1]), cb = wave_sum(w * col[2]);
+    const float dzD = z - D;
+    const float V = wave_sum(w * dzD * dzD);
+    if (A.weights && act) A.weights[m] = w;
+    if (lane == 0) {
+        if (A.depth) A.depth[n] = D;
+        if (A.var) A.var[n] = V;
+        if (A.rgb) { A.rgb[3 * n] = cr; A.rgb[3 * n + 1] = cg; A.rgb[3 * n + 2] = cb; }
+    }
+    if (A.mode == 0) return;
+    // ---- seed gradients -------------------------------------------------------------------------------
+    float gD = 0.f, gV = 0.f, gC[3] = {0.f, 0.f, 0.f};
+    if (A.mode == 1) {
+        gD = A.g_depth ? A.g_depth[n] : 0.f;
+        gV = A.g_var ? A.g_var[n] : 0.f;
+        gC[0] = A.g_rgb[3 * n]; gC[1] = A.g_rgb[3 * n + 1]; gC[2] = A.g_rgb[3 * n + 2];
+    } else {
+        const float gtd = A.gt_depth[n];
+        const float r = gtd - D;
+        float rc[3] = {0.f, 0.f, 0.f};
+        if (A.use_color) { rc[0] = A.gt_color[3 * n] - cr; rc[1] = A.gt_color[3 * n + 1] - cg; rc[2] = A.gt_color[3 * n + 2] - cb; }
+        float lsum = 0.f;
+        if (A.mode == 2) {                                      // Mapper.cpp:435-442
+            if (gtd > 0.f) { lsum += fabsf(r); gD = -sgnf(r); }
+            if (A.use_color) {
+                lsum += A.w_color * (fabsf(rc[0]) + fabsf(rc[1]) + fabsf(rc[2]));
+                for (int k = 0; k < 3; ++k) gC[k] = -A.w_color * sgnf(rc[k]);
+            }
+        } else {                                                // Tracker.cpp:67-82
+            bool mk = gtd > 0.f && (!A.handle_dynamic || fabsf(r) < *A.thr);
+            if (mk) {
+                float u = sqrtf(V + 1e-10f);
+                lsum += fabsf(r) / u;
+                gD = -sgnf(r) / u;
+                if (!A.detach_var) gV = -fabsf(r) / (2.f * u * u * u);
+                if (A.use_color) {
+                    lsum += A.w_color * (fabsf(rc[0]) + fabsf(rc[1]) + fabsf(rc[2]));
+                    for (int k = 0; k < 3; ++k) gC[k] = -A.w_color * sgnf(rc[k]);
+                }
+            }
+        }
+        if (A.loss && lane == 0) A.loss[n] = lsum;               // per-ray loss, summed by k_sum
+    }
+    // ---- backward of the compositing (SURVEY.md 8a "Backward formulas") -------------------------------
+    gD += gV * -2.f * wave_sum(w * dzD);
+    float v = gD * z + gV * dzD * dzD + gC[0] * col[0] + gC[1] * col[1] + gC[2] * col[2];
+    float vw = act ? v * w : 0.f;
+    // exclusive suffix sum of v*w
+    float suf = vw;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float dn = __shfl_down(suf, o);
+        if (lane + o < 64) suf += dn;
+    }
+    suf -= vw;
+    float g_alpha = v * T - suf / (1.f - alpha + 1e-10f);
+    float g_sigma, g_n = 0.f;
+    if (A.R.occupancy) g_sigma = g_alpha * 10.f * alpha * (1.f - alpha);
+    else {
+        float rs = fmaxf(sg, 0.f);
+        g_sigma = sg > 0.f ? g_alpha * dist * ex : 0.f;
+        g_n = g_alpha * rs * ex * dzv;
+    }
+    if (!inb) g_sigma = 0.f;
+    if (act) *reinterpret_cast<f4*>(A.g_raw + m * 4) = (f4){w * gC[0], w * gC[1], w * gC[2], g_sigma};
+    if (A.g_rays_d) {
+        float gn = wave_sum(act ? g_n : 0.f);
+        if (lane < 3) {
+            float dk = lane == 0 ? dx : (lane == 1 ? dy : dz);
+            A.g_rays_d[3 * n + lane] = nrm > 0.f ? gn * dk / nrm : 0.f;      // utils.h:153 norm(rays_d)
+            A.g_rays_o[3 * n + lane] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// scatter-add of a 16-sample tile's feature gradient into the grid gradient (voxel-major).  The tile is
+// transposed through per-wave LDS scratch so that each atomic wave-instruction adds two full 128-byte voxel
+// lines (the full-rate shape of global_atomic_add_f32, MI355X guide "Global float atomics").
+// scratch: gct[16][36] floats + vox[16][8] ints + wts[16][8] floats  (3328 bytes)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const f4 (&gc)[2], int lane, bool valid,
+                                             float* __restrict__ scratch)
+{
+    const int j = lane & 15, g = lane >> 4;
+    float* gct = scratch;                                   // [16][36]
+    int* vx = reinterpret_cast<int*>(scratch + 16 * 36);    // [16][8]
+    float* wt = scratch + 16 * 36 + 128;                    // [16][8]
+    *reinterpret_cast<f4*>(gct + j * 36 + 4 * g) = valid ? gc[0] : (f4)(0.f);
+    *reinterpret_cast<f4*>(gct + j * 36 + 16 + 4 * g) = valid ? gc[1] : (f4)(0.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if ((c >> 1) == g) { vx[j * 8 + c] = T.vox[c]; wt[j * 8 + c] = valid ? T.w[c] : 0.f; }
+    lds_fence();
+    const int ch = lane & 31, sh = lane >> 5;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int jj = 2 * it + sh;
+        const float v = gct[jj * 36 + ch];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float w = wt[jj * 8 + c];
+            const int vox = vx[jj * 8 + c];
+            const float add = w * v;
+            if (add != 0.f && (!G.mask || G.mask[vox])) atomicAdd(G.g + (size_t)vox * 32 + ch, add);
+        }
+    }
+    lds_fence();
+}
+
+// spatial derivative of the trilinear lookup contracted with g_c: returns this lane's partial (its 8 channels)
+__device__ __forceinline__ void tri_grad_p(const GridD& G, const Tri& T, int g, const f4 (&gc)[2], float (&gp)[3])
+{
+    float gi[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+        // out-of-grid corners carry value 0 in the reference (their weight is 0 and the axis is clipped)
+        const f4* vp = reinterpret_cast<const f4*>(G.v + (size_t)T.vox[c] * 32 + 4 * g);
+        f4 a = vp[0], b = vp[4];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dot += a[i] * gc[0][i] + b[i] * gc[1][i];
+        float wx = dx ? T.t[0] : 1.f - T.t[0], wy = dy ? T.t[1] : 1.f - T.t[1], wz = dz ? T.t[2] : 1.f - T.t[2];
+        gi[0] += (dx ? dot : -dot) * wy * wz;
+        gi[1] += (dy ? dot : -dot) * wx * wz;
+        gi[2] += (dz ? dot : -dot) * wx * wy;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gp[k] += gi[k] * T.gmul[k];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per-workgroup accumulation of decoder weight gradients: dW[o][x] += sum_samples G[o][s] X[x][s].
+// G (32 rows) and a 16-row chunk of X are transposed through per-wave LDS scratch ([row][20]) and contracted
+// over the tile's 16 samples with four MFMA steps; the 16x16 result is added into the workgroup's LDS
+// accumulator (canonical parameter layout) with ds_add_f32.
+// ------------------------------------------------------------------------------------------------------
+#define TG_LD 20
+// write one D-layout quad (16 feature rows x 16 samples) transposed: dst[row][sample]
+__device__ __forceinline__ void wg_put_quad(float* __restrict__ dst, int lane, f4 x)
+{
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[(4 * g + i) * TG_LD + j] = x[i];
+}
+
+// D[o][x] for G row tile rt (rows 16rt..) and the X chunk currently in tx
+__device__ __forceinline__ f4 wg_outer(const float* __restrict__ tg, const float* __restrict__ tx, int rt, int lane)
+{
+    const int r = lane & 15, sq = lane >> 4;
+    f4 a = *reinterpret_cast<const f4*>(tg + (16 * rt + r) * TG_LD + 4 * sq);
+    f4 b = *reinterpret_cast<const f4*>(tx + r * TG_LD + 4 * sq);
+    f4 d = (f4)(0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d = mfma4(a[i], b[i], d);
+    return d;
+}
+
+// add tile D (rows o = 16rt+4g+i, col x = lane&15) into acc[base + o*ld + col0 + x] for o < rows, x < cols
+__device__ __forceinline__ void wg_add(float* __restrict__ acc, int base, int ld, int col0, int rows, int cols, int rt,
+                                       int lane, f4 d)
+{
+    const int x = lane & 15, g = lane >> 4;
+    if (x < cols) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int o = 16 * rt + 4 * g + i;
+            if (o < rows) atomicAdd(acc + base + o * ld + col0 + x, d[i]);
+        }
+    }
+}
+
+// one X chunk against both G row tiles
+__device__ __forceinline__ void wg_chunk(float* __restrict__ acc, int base, int ld, int col0, int rows, int cols,
+                                         const float* __restrict__ tg, float* __restrict__ tx, int lane, f4 xq)
+{
+    wg_put_quad(tx, lane, xq);
+    lds_fence();
+    f4 d0 = wg_outer(tg, tx, 0, lane);
+    f4 d1 = (f4)(0.f);
+    if (rows > 16) d1 = wg_outer(tg, tx, 1, lane);
+    lds_fence();
+    wg_add(acc, base, ld, col0, rows, cols, 0, lane, d0);
+    if (rows > 16) wg_add(acc, base, ld, col0, rows, cols, 1, lane, d1);
+}
+
+// row sums over the tile's samples: acc[base + o] += sum_s G[o][s]
+__device__ __forceinline__ void wg_add_rowsum(float* __restrict__ acc, int base, int rows, const float* __restrict__ tg,
+                                              int lane)
+{
+    const int r = lane & 15, sq = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        if (16 * rt < rows) {
+            f4 a = *reinterpret_cast<const f4*>(tg + (16 * rt + r) * TG_LD + 4 * sq);
+            f4 d = (f4)(0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d = mfma4(a[i], 1.0f, d);
+            if (r == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int o = 16 * rt + 4 * sq + i;
+                    if (o < rows) atomicAdd(acc + base + o, d[i]);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wg_zero_tg(float* __restrict__ tg, int lane)
+{
+    for (int r = lane; r < 32 * TG_LD; r += 64) tg[r] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4: decoder backward over 16-sample tiles.
+//   TRAIN=false: "light" backward of a frozen decoder from the saved ReLU bits: g_out -> g_c (-> grid
+//                gradient scatter) [-> g_p for NSK_GRAD_RAYS].  LDS holds the backward image.
+//   TRAIN=true : recompute the forward (forward image in LDS; fine: streamed from L2 because image +
+//                accumulator exceed 160 KiB), then the same chain with backward fragments streamed from L2,
+//                plus all parameter gradients accumulated per workgroup in LDS and flushed once with atomics.
+// ------------------------------------------------------------------------------------------------------
+template <int WHICH, bool TRAIN, bool RAYS>
+__global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A)
+{
+    constexpr bool XYZ = WHICH != 0;
+    constexpr int CQ = WHICH == 2 ? 4 : 2;
+    constexpr int OD = WHICH == 3 ? 4 : 1;
+    constexpr bool NEED_E = XYZ && (TRAIN || RAYS);
+    constexpr bool FWD_LDS = TRAIN && WHICH != 2;
+    typedef MlpFwdImg<CQ> FI;
+    constexpr int FWD_F = XYZ ? FI::TOTAL : CoarseFwdImg::TOTAL;
+    constexpr int BWD_F = XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL;
+    constexpr int IMG_F = TRAIN ? (FWD_LDS ? FWD_F : 0) : BWD_F;
+    constexpr DecLayoutDev L = dec_layout_dev<WHICH>();
+    constexpr int NPAR = L.total;
+    constexpr int NPAR4 = TRAIN ? ((NPAR + 3) & ~3) : 0;
+    extern __shared__ __attribute__((aligned(16))) f4 smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    // LDS carve: [image][dW accumulator (TRAIN)][per-wave scratch 3840 B]
+    float* smf = reinterpret_cast<float*>(smem);
+    float* dacc = smf + IMG_F;
+    float* scratch = dacc + NPAR4 + wave * 960;
+    {
+        const f4* src = TRAIN ? A.img : A.bimg;
+        for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = src[i];
+        for (int i = threadIdx.x; i < NPAR4; i += 512) dacc[i] = 0.f;
+    }
+    __syncthreads();
+    const f4* fimg = FWD_LDS ? smem : A.img;
+    const float* fimgf = reinterpret_cast<const float*>(fimg);
+    const f4* bimg = TRAIN ? A.bimg : smem;
+    const float* bimgf = reinterpret_cast<const float*>(bimg);
+    const float* Bm = nullptr;
+    if constexpr (XYZ) Bm = TRAIN ? fimgf + FI::P_BM : bimgf + MlpBwdImg::P_BM;
+    const float* Wo = TRAIN ? (XYZ ? fimgf + FI::P_WO : fimgf + CoarseFwdImg::P_WO)
+                            : (XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO);
+    float* tg = scratch;                  // [32][20]
+    float* tx = scratch + 32 * TG_LD;     // [16][20]
+
+    const int ntasks = (A.M + 15) >> 4;
+    for (int task = blockIdx.x * 8 + wave; task < ntasks; task += gridDim.x * 8) {
+        asm volatile("" ::: "memory");      // keep the LDS fragment reads inside the loop (LICM would hoist + spill them)
+        const int m = task * 16 + j;
+        const bool valid = m < A.M;
+        const int mm = min(m, A.M - 1);
+        float px, py, pz, zz; int n;
+        sample_point(A, mm, px, py, pz, zz, n);
+        Tri T;
+        tri_setup(A.grid, A.bound, px, py, pz, T);
+        // upstream gradient of this decoder's output
+        float gout[OD];
+        {
+            f4 gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+            if (!valid) gr = (f4)(0.f);
+            if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
+            else gout[0] = gr[3];
+        }
+        // activations (TRAIN) or saved ReLU bits (frozen)
+        Act<CQ> C;
+        ActC CC;
+        f4 xcos[6];
+        unsigned long long mask;
+        if constexpr (TRAIN) {
+            if constexpr (XYZ) {
+                tri_gather(A.grid, T, g, C.xc[0], C.xc[1]);
+                if constexpr (WHICH == 2) {
+                    Tri Tm;
+                    tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
+                    tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
+                }
+                embed<true>(Bm, g, px, py, pz, C.xe, xcos);
+                mlp_forward<CQ>(fimg, lane, C);
+                mask = C.mask;
+            } else {
+                tri_gather(A.grid, T, g, CC.xc[0], CC.xc[1]);
+                coarse_forward(fimg, lane, CC);
+                mask = CC.mask;
+            }
+        } else {
+            mask = A.masks[(size_t)mm * 4 + g];
+            if constexpr (NEED_E) { f4 e[6]; embed<true>(Bm, g, px, py, pz, e, xcos); }
+        }
+        // g_h4 = Wo^T g_out
+        f4 gh[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < OD; ++o) s += Wo[32 * o + 16 * r + 4 * g + i] * gout[o];
+                gh[r][i] = s;
+            }
+        if constexpr (TRAIN) {   // d output_linear
+            wg_zero_tg(tg, lane);
+            lds_fence();
+            if (g == 0) {
+#pragma unroll
+                for (int o = 0; o < OD; ++o) tg[o * TG_LD + j] = gout[o];
+            }
+            lds_fence();
+            wg_add_rowsum(dacc, L.obo, OD, tg, lane);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f4 hq;
+                if constexpr (XYZ) hq = C.h[4][q]; else hq = CC.h[4][q];
+                wg_chunk(dacc, L.oWo, 32, 16 * q, OD, 16, tg, tx, lane, hq);
+            }
+        }
+        f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
+        f4 ge[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
+#pragma unroll
+        for (int l = 4; l >= 0; --l) {
+            if constexpr (XYZ) gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);            // g_c += fc[l]^T g_h
+            f4 ga[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
+            if constexpr (TRAIN) {
+                if constexpr (XYZ) {       // d fc[l] = g_h c^T, d fc_bias[l] = sum g_h
+                    wg_put_quad(tg, lane, gh[0]);
+                    wg_put_quad(tg + 16 * TG_LD, lane, gh[1]);
+                    lds_fence();
+                    wg_add_rowsum(dacc, L.oFb[l], 32, tg, lane);
+#pragma unroll
+                    for (int q = 0; q < CQ; ++q) wg_chunk(dacc, L.oFw[l], 16 * CQ, 16 * q, 32, 16, tg, tx, lane, C.xc[q]);
+                }
+                // d pts_linear[l] = g_a x^T, bias = sum g_a
+                wg_put_quad(tg, lane, ga[0]);
+                wg_put_quad(tg + 16 * TG_LD, lane, ga[1]);
+                lds_fence();
+                wg_add_rowsum(dacc, L.ob[l], 32, tg, lane);
+                const int nx = L.in_dim[l];
+                if constexpr (XYZ) {
+                    if (l == 0 || l == 3) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+                            wg_chunk(dacc, L.oW[l], nx, 16 * q, 32, (NSK_E - 16 * q) < 16 ? (NSK_E - 16 * q) : 16, tg, tx, lane, C.xe[q]);
+                    }
+                    if (l != 0) {
+                        const int col0 = l == 3 ? NSK_E : 0;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) wg_chunk(dacc, L.oW[l], nx, col0 + 16 * q, 32, 16, tg, tx, lane, C.h[l > 0 ? l - 1 : 0][q]);
+                    }
+                } else {
+                    if (l == 0 || l == 3) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) wg_chunk(dacc, L.oW[l], nx, 16 * q, 32, 16, tg, tx, lane, CC.xc[q]);
+                    }
+                    if (l != 0) {
+                        const int col0 = l == 3 ? 32 : 0;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) wg_chunk(dacc, L.oW[l], nx, col0 + 16 * q, 32, 16, tg, tx, lane, CC.h[l > 0 ? l - 1 : 0][q]);
+                    }
+                }
+            }
+            if constexpr (XYZ) {
+                if constexpr (NEED_E) {
+                    if (l == 3) gemm<6, 2>(bimg, MlpBwdImg::W3ET, lane, ga, ge);
+                    if (l == 0) gemm<6, 2>(bimg, MlpBwdImg::W0ET, lane, ga, ge);
+                }
+                if (l >= 1) {
+                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
+                    gemm<2, 2>(bimg, MlpBwdImg::WT(l > 0 ? l : 1), lane, ga, ghn);
+                    gh[0] = ghn[0]; gh[1] = ghn[1];
+                }
+            } else {
+                if (l == 3) gemm<2, 2>(bimg, CoarseBwdImg::W3CT, lane, ga, gc);
+                if (l == 0) gemm<2, 2>(bimg, CoarseBwdImg::W0T, lane, ga, gc);
+                else {
+                    const int q0 = l == 1 ? CoarseBwdImg::W1T : (l == 2 ? CoarseBwdImg::W2T : (l == 3 ? CoarseBwdImg::W3HT : CoarseBwdImg::W4T));
+                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
+                    gemm<2, 2>(bimg, q0, lane, ga, ghn);
+                    gh[0] = ghn[0]; gh[1] = ghn[1];
+                }
+            }
+        }
+        // embedding backward: g_s = g_e * cos(pB);  dB = p^T g_s;  g_p += g_s B^T
+        float gp[3] = {0.f, 0.f, 0.f};
+        if constexpr (NEED_E) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ge[q] *= xcos[q];
+            if constexpr (TRAIN) {
+                wg_zero_tg(tg, lane);
+                lds_fence();
+                if (g == 0) { tg[0 * TG_LD + j] = valid ? px : 0.f; tg[1 * TG_LD + j] = valid ? py : 0.f; tg[2 * TG_LD + j] = valid ? pz : 0.f; }
+                lds_fence();
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    wg_chunk(dacc, L.oB, NSK_E, 16 * q, 3, (NSK_E - 16 * q) < 16 ? (NSK_E - 16 * q) : 16, tg, tx, lane, ge[q]);
+            }
+            if constexpr (RAYS) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    f4 b0 = *reinterpret_cast<const f4*>(Bm + 16 * q + 4 * g);
+                    f4 b1 = *reinterpret_cast<const f4*>(Bm + 96 + 16 * q + 4 * g);
+                    f4 b2 = *reinterpret_cast<const f4*>(Bm + 192 + 16 * q + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { gp[0] += ge[q][i] * b0[i]; gp[1] += ge[q][i] * b1[i]; gp[2] += ge[q][i] * b2[i]; }
+                }
+            }
+        }
+        if constexpr (RAYS) {
+            tri_grad_p(A.grid, T, g, gc, gp);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gp[k] += __shfl_xor(gp[k], 16); gp[k] += __shfl_xor(gp[k], 32); }
+            if (g == 0 && valid && A.g_rays_o) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    atomicAdd(A.g_rays_o + 3 * n + k, gp[k]);
+                    atomicAdd(A.g_rays_d + 3 * n + k, gp[k] * zz);
+                }
+            }
+        }
+        if ((A.flags & 1u) && A.grid.g) scatter_tile(A.grid, T, gc, lane, valid, scratch);
+    }
+    if constexpr (TRAIN) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < NPAR; i += 512) {
+            float v = dacc[i];
+            if (v != 0.f) atomicAdd(A.g_dec + i, v);
+        }
+    }
+}

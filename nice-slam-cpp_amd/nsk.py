@@ -1,0 +1,298 @@
+"""ctypes binding of the C-ABI in include/nsk.h (libnsk.so, built from csrc/ for gfx950).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is present, creating a context raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "csrc", "libnsk.so")
+
+STAGES = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
+LEVELS = ("coarse", "middle", "fine", "color")
+GRAD_GRIDS, GRAD_DECODERS, GRAD_RAYS = 1, 2, 4
+GROUP_DECODERS, GROUP_COARSE, GROUP_MIDDLE, GROUP_FINE, GROUP_COLOR, GROUP_CAMERA = range(6)
+
+# every symbol include/nsk.h declares
+SYMBOLS = (
+    "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
+    "nsk_set_render_opts", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask",
+    "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
+    "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_render_backward", "nsk_map_step",
+    "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
+    "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
+    "nsk_adam_reset", "nsk_zero_grads", "nsk_grad_slab", "nsk_allreduce_grads", "nsk_last_call_stats",
+)
+
+
+class NskError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)"""
+    src = [os.path.join(_HERE, "csrc", f) for f in ("nsk.hip", "nsk_device.h", "nsk_layout.h")]
+    src.append(os.path.join(_HERE, "..", "include", "nsk.h"))
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "all"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NskError("libnsk.so is not built (%s); run __graft_entry__.build() -- there is no fallback path" % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        L.nsk_last_error.restype = C.c_char_p
+        L.nsk_decoder_param_count.restype = C.c_size_t
+        L.nsk_decoder_param_count.argtypes = [C.c_int]
+        L.nsk_stream.restype = C.c_void_p
+        L.nsk_stream.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise NskError(lib().nsk_last_error().decode())
+
+
+def _ptr(t):
+    """device pointer of a contiguous torch CUDA tensor (or None)"""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "expected a contiguous CUDA tensor"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stage(s):
+    return STAGES[s] if isinstance(s, str) else int(s)
+
+
+class _CudaArray:
+    """__cuda_array_interface__ view of a raw device pointer so that torch can wrap context-owned memory"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class Context:
+    """one nsk_ctx (one GPU, one HIP stream)"""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        _chk(lib().nsk_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().nsk_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------------------------------
+    def set_bound(self, bound):
+        import numpy as np
+        b = np.ascontiguousarray(np.asarray(bound, dtype=np.float32).reshape(6))
+        _chk(lib().nsk_set_bound(self.h, b.ctypes.data_as(C.c_void_p)))
+
+    def set_render_opts(self, n_samples=32, n_surface=16, lindisp=False, perturb=0.0, occupancy=False, seed=0):
+        _chk(lib().nsk_set_render_opts(self.h, n_samples, n_surface, int(lindisp), C.c_float(perturb), int(occupancy),
+                                       C.c_uint64(seed)))
+        self.n_samples, self.n_surface = n_samples, n_surface
+
+    def sync(self):
+        _chk(lib().nsk_sync(self.h))
+
+    # -- grids / decoders (host numpy in the reference layouts) ------------------------------------------
+    def grid_upload(self, level, arr):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+        if a.ndim == 5:
+            a = a[0]
+        Cc, Z, Y, X = a.shape
+        _chk(lib().nsk_grid_upload(self.h, _stage(level), a.ctypes.data_as(C.c_void_p), Cc, Z, Y, X))
+        if not hasattr(self, "_gshape"):
+            self._gshape = {}
+        self._gshape[_stage(level)] = (Cc, Z, Y, X)
+
+    def grid_download(self, level, grad=False):
+        import numpy as np
+        out = np.zeros(self._gshape[_stage(level)], np.float32)
+        f = lib().nsk_grid_grad_download if grad else lib().nsk_grid_download
+        _chk(f(self.h, _stage(level), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_mask(self, level, mask):
+        import numpy as np
+        if mask is None:
+            _chk(lib().nsk_set_mask(self.h, _stage(level), None))
+            return
+        m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        _chk(lib().nsk_set_mask(self.h, _stage(level), m.ctypes.data_as(C.c_void_p)))
+
+    def decoder_upload(self, which, packed):
+        import numpy as np
+        p = np.ascontiguousarray(np.asarray(packed, dtype=np.float32).reshape(-1))
+        _chk(lib().nsk_decoder_upload(self.h, _stage(which), p.ctypes.data_as(C.c_void_p), C.c_size_t(p.size)))
+
+    def decoder_download(self, which, grad=False):
+        import numpy as np
+        n = lib().nsk_decoder_param_count(_stage(which))
+        out = np.zeros(n, np.float32)
+        f = lib().nsk_decoder_grad_download if grad else lib().nsk_decoder_download
+        _chk(f(self.h, _stage(which), out.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        return out
+
+    def decoder_set_trainable(self, which, flag):
+        _chk(lib().nsk_decoder_set_trainable(self.h, _stage(which), int(flag)))
+
+    def load_scene(self, bound, grids, decoders):
+        self.set_bound(bound)
+        for k in LEVELS:
+            if k in grids and grids[k] is not None:
+                self.grid_upload(k, grids[k])
+            if k in decoders and decoders[k] is not None:
+                self.decoder_upload(k, decoders[k])
+
+    # -- rendering (torch CUDA tensors in, torch CUDA tensors out) ------------------------------------------
+    def _S(self, gt_depth):
+        return getattr(self, "n_samples", 32) + (getattr(self, "n_surface", 16) if gt_depth is not None else 0)
+
+    def render_forward(self, stage, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0, want_weights=True):
+        import torch
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        rgb = torch.empty(N, 3, device=dev); depth = torch.empty(N, device=dev); var = torch.empty(N, device=dev)
+        w = torch.empty(N, self._S(gt_depth), device=dev) if want_weights else None
+        _chk(lib().nsk_render_forward(self.h, _stage(stage), N, _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth),
+                                      C.c_float(gt_depth_max), _ptr(rgb), _ptr(depth), _ptr(var), _ptr(w)))
+        return rgb, depth, var, w
+
+    def eval_points(self, stage, pts):
+        import torch
+        M = pts.shape[0]
+        raw = torch.empty(M, 4, device=pts.device)
+        _chk(lib().nsk_eval_points(self.h, _stage(stage), M, _ptr(pts), _ptr(raw)))
+        return raw
+
+    def render_backward(self, stage, rays_o, rays_d, gt_depth, gt_depth_max, g_rgb, g_depth, g_var=None, flags=GRAD_GRIDS):
+        import torch
+        N = rays_o.shape[0]
+        g_ro = g_rd = None
+        if flags & GRAD_RAYS:
+            g_ro = torch.empty(N, 3, device=rays_o.device); g_rd = torch.empty(N, 3, device=rays_o.device)
+        _chk(lib().nsk_render_backward(self.h, _stage(stage), N, _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth),
+                                       C.c_float(gt_depth_max), _ptr(g_rgb), _ptr(g_depth), _ptr(g_var), C.c_uint(flags),
+                                       _ptr(g_ro), _ptr(g_rd)))
+        return g_ro, g_rd
+
+    def map_step(self, stage, rays_o, rays_d, gt_depth, gt_color, gt_depth_max=-1.0, w_color=0.2, use_color=True,
+                 flags=GRAD_GRIDS | GRAD_DECODERS, loss=None, outputs=None, g_rays=None):
+        N = rays_o.shape[0]
+        rgb, depth, var = outputs if outputs is not None else (None, None, None)
+        g_ro, g_rd = g_rays if g_rays is not None else (None, None)
+        _chk(lib().nsk_map_step(self.h, _stage(stage), N, _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), _ptr(gt_color),
+                                C.c_float(gt_depth_max), C.c_float(w_color), int(use_color), C.c_uint(flags), _ptr(loss),
+                                _ptr(rgb), _ptr(depth), _ptr(var), _ptr(g_ro), _ptr(g_rd)))
+
+    def track_step(self, stage, rays_o, rays_d, gt_depth, gt_color, gt_depth_max=-1.0, w_color=0.5, use_color=True,
+                   handle_dynamic=True, detach_var=True, flags=GRAD_RAYS, loss=None, g_rays=None):
+        N = rays_o.shape[0]
+        g_ro, g_rd = g_rays if g_rays is not None else (None, None)
+        _chk(lib().nsk_track_step(self.h, _stage(stage), N, _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), _ptr(gt_color),
+                                  C.c_float(gt_depth_max), C.c_float(w_color), int(use_color), int(handle_dynamic),
+                                  int(detach_var), C.c_uint(flags), _ptr(loss), _ptr(g_ro), _ptr(g_rd)))
+
+    def loss_map(self, depth, rgb, gt_depth, gt_color, w_color, use_color):
+        import torch
+        N = depth.shape[0]
+        g_d = torch.empty(N, device=depth.device); g_c = torch.empty(N, 3, device=depth.device)
+        loss = torch.zeros(1, device=depth.device)
+        _chk(lib().nsk_loss_map(self.h, N, _ptr(depth), _ptr(rgb), _ptr(gt_depth), _ptr(gt_color), C.c_float(w_color),
+                                int(use_color), _ptr(g_d), _ptr(g_c), _ptr(loss)))
+        return loss, g_d, g_c
+
+    def loss_track(self, depth, rgb, var, gt_depth, gt_color, w_color, use_color, handle_dynamic, detach_var=True):
+        import torch
+        N = depth.shape[0]
+        dev = depth.device
+        g_d = torch.empty(N, device=dev); g_c = torch.empty(N, 3, device=dev); g_v = torch.empty(N, device=dev)
+        loss = torch.zeros(1, device=dev)
+        _chk(lib().nsk_loss_track(self.h, N, _ptr(depth), _ptr(rgb), _ptr(var), _ptr(gt_depth), _ptr(gt_color),
+                                  C.c_float(w_color), int(use_color), int(handle_dynamic), int(detach_var), _ptr(g_d),
+                                  _ptr(g_c), _ptr(g_v), _ptr(loss)))
+        return loss, g_d, g_c, g_v
+
+    # -- rays / pose ------------------------------------------------------------------------------------------
+    def rays_from_pixels(self, pix_i, pix_j, intr, c2w, mode=0):
+        import torch
+        n = pix_i.shape[0]
+        ro = torch.empty(n, 3, device=c2w.device); rd = torch.empty(n, 3, device=c2w.device)
+        fx, fy, cx, cy = intr
+        _chk(lib().nsk_rays_from_pixels(self.h, n, _ptr(pix_i), _ptr(pix_j), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                        C.c_float(cy), _ptr(c2w), mode, _ptr(ro), _ptr(rd)))
+        return ro, rd
+
+    def rays_backward(self, pix_i, pix_j, intr, g_ro, g_rd, mode=0):
+        import torch
+        g = torch.empty(3, 4, device=g_ro.device)
+        fx, fy, cx, cy = intr
+        _chk(lib().nsk_rays_backward(self.h, pix_i.shape[0], _ptr(pix_i), _ptr(pix_j), C.c_float(fx), C.c_float(fy),
+                                     C.c_float(cx), C.c_float(cy), mode, _ptr(g_ro), _ptr(g_rd), _ptr(g)))
+        return g
+
+    def camera_from_tensor(self, cam):
+        import torch
+        c2w = torch.empty(3, 4, device=cam.device)
+        _chk(lib().nsk_camera_from_tensor(self.h, _ptr(cam), _ptr(c2w)))
+        return c2w
+
+    def camera_backward(self, cam, g_c2w):
+        import torch
+        g = torch.empty(7, device=cam.device)
+        _chk(lib().nsk_camera_backward(self.h, _ptr(cam), _ptr(g_c2w), _ptr(g)))
+        return g
+
+    def inside_filter(self, rays_o, rays_d, gt_depth):
+        import torch
+        keep = torch.empty(rays_o.shape[0], dtype=torch.uint8, device=rays_o.device)
+        _chk(lib().nsk_inside_filter(self.h, rays_o.shape[0], _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), _ptr(keep)))
+        return keep.bool()
+
+    def adam_vector(self, p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+        _chk(lib().nsk_adam_vector(self.h, p.numel(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_float(lr), C.c_float(b1),
+                                   C.c_float(b2), C.c_float(eps), int(step)))
+
+    # -- optimiser / multi-GPU ----------------------------------------------------------------------------------
+    def adam_step(self, lr, b1=0.9, b2=0.999, eps=1e-8):
+        arr = (C.c_float * 6)(*[float(x) for x in lr])
+        _chk(lib().nsk_adam_step(self.h, arr, C.c_float(b1), C.c_float(b2), C.c_float(eps)))
+
+    def adam_reset(self):
+        _chk(lib().nsk_adam_reset(self.h))
+
+    def zero_grads(self):
+        _chk(lib().nsk_zero_grads(self.h))
+
+    def grad_slab(self):
+        """the contiguous gradient slab as a torch tensor aliasing context memory (for torch.distributed all-reduce)"""
+        import torch
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(lib().nsk_grad_slab(self.h, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_CudaArray(p.value, n.value), device="cuda:%d" % self.device)
+
+    def last_call_stats(self):
+        b, f, s = C.c_double(), C.c_double(), C.c_int()
+        _chk(lib().nsk_last_call_stats(self.h, C.byref(b), C.byref(f), C.byref(s)))
+        return b.value, f.value, s.value

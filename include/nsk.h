@@ -182,6 +182,10 @@ int nsk_allreduce_grads(nsk_ctx* ctx, void* nccl_comm);
 /* ---- introspection for benchmarks ------------------------------------------------------------------------ */
 /* algorithmic bytes / flops of the last render or step call (SURVEY.md section 8d accounting) */
 int nsk_last_call_stats(nsk_ctx* ctx, double* alg_bytes, double* alg_flops, int* samples);
+/* per-kernel timing with HIP events recorded on the context's stream around every launch between
+ * nsk_profile_begin and nsk_profile_end; _end synchronises and writes "name launches total_ms\n" lines. */
+int nsk_profile_begin(nsk_ctx* ctx);
+int nsk_profile_end(nsk_ctx* ctx, char* buf, size_t buf_bytes);
 
 #ifdef __cplusplus
 }

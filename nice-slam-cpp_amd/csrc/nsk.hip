@@ -265,6 +265,26 @@ struct nsk_ctx {
     int adam_step[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
+    // optional per-kernel timing with HIP events on the context's stream (nsk_profile_begin / _end)
+    bool prof = false;
+    struct ProfRec { const char* name; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+};
+
+struct ProfScope {      // records start/stop events around the launches issued while it is alive
+    nsk_ctx* c; hipEvent_t a = nullptr, b = nullptr; const char* name;
+    ProfScope(nsk_ctx* c_, const char* n) : c(c_), name(n)
+    {
+        if (!c->prof) return;
+        hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!c->prof || !a) return;
+        hipEventRecord(b, c->stream);
+        c->prof_recs.push_back({name, a, b});
+    }
 };
 
 extern "C" const char* nsk_last_error(void) { return g_err.c_str(); }
@@ -518,6 +538,7 @@ static void build_idx(int w, std::vector<int>& fidx, std::vector<int>& bidx)
 static int repack(nsk_ctx* c, int w)
 {
     DecState& D = c->dec[w];
+    ProfScope ps(c, "pack_images");
     k_pack<<<(D.fimg_n + 255) / 256, 256, 0, c->stream>>>(D.fimg, D.fidx, D.p, D.fimg_n);
     k_pack<<<(D.bimg_n + 255) / 256, 256, 0, c->stream>>>(D.bimg, D.bidx, D.p, D.bimg_n);
     HIPCHK(hipGetLastError());
@@ -646,6 +667,8 @@ static int launch_decode_fwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     size_t lds = fwd_img_floats(w) * 4;
     int maxwg = c->num_cu * (lds <= 80 * 1024 ? 2 : 1);
     int grid = std::max(1, std::min((ntasks + 7) / 8, maxwg));
+    static const char* names[4] = {"decode_fwd_coarse", "decode_fwd_middle", "decode_fwd_fine", "decode_fwd_color"};
+    ProfScope ps(c, names[w]);
     switch (w) {
     case 0: k_decode_fwd<0><<<grid, 512, lds, c->stream>>>(A); break;
     case 1: k_decode_fwd<1><<<grid, 512, lds, c->stream>>>(A); break;
@@ -670,6 +693,9 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     int ntasks = (M + 15) / 16;
     size_t lds = bwd_lds_bytes(w, train);
     int grid = std::max(1, std::min((ntasks + 7) / 8, c->num_cu));
+    static const char* names[8] = {"decode_bwd_coarse", "decode_bwd_middle", "decode_bwd_fine", "decode_bwd_color",
+                                   "decode_bwd_coarse_train", "decode_bwd_middle_train", "decode_bwd_fine_train", "decode_bwd_color_train"};
+    ProfScope ps(c, names[w + (train ? 4 : 0)]);
 #define LB(W) \
     if (train) { if (rays) k_decode_bwd<W, true, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd<W, true, false><<<grid, 512, lds, c->stream>>>(A); } \
     else { if (rays) k_decode_bwd<W, false, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd<W, false, false><<<grid, 512, lds, c->stream>>>(A); }
@@ -704,10 +730,14 @@ static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, co
     const int M = N * S;
     const float* gmax_dev = nullptr;
     if (gt && gtmax < 0.f) {
+        ProfScope ps(c, "depth_max");
         k_depth_max<<<1, 1024, 0, c->stream>>>(N, gt, c->scal);
         gmax_dev = c->scal;
     }
+    {
+    ProfScope ps(c, "sample");
     k_sample<<<(N + 3) / 4, 256, 0, c->stream>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, c->ws.z);
+    }
     HIPCHK(hipGetLastError());
     for (int q = 0; q < 3; ++q) {
         int w = STAGE_DEC[stage][q];
@@ -750,7 +780,7 @@ extern "C" int nsk_render_forward(nsk_ctx* c, int stage, int N, const float* ro,
     CompArgs A;
     comp_args(c, A, stage, N, S, ro, rd);
     A.rgb = rgb; A.depth = depth; A.var = var; A.weights = weights; A.mode = 0;
-    k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());
     account(c, stage, N * S, N, false, 0);
     return 0;
@@ -804,7 +834,7 @@ extern "C" int nsk_render_backward(nsk_ctx* c, int stage, int N, const float* ro
     comp_args(c, A, stage, N, S, ro, rd);
     A.mode = 1; A.g_rgb = g_rgb; A.g_depth = g_depth; A.g_var = g_var;
     if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
-    k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());
     CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
     account(c, stage, N * S, N, true, flags);
@@ -826,9 +856,9 @@ extern "C" int nsk_map_step(nsk_ctx* c, int stage, int N, const float* ro, const
     A.mode = 2; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
     A.rgb = rgb; A.depth = depth; A.var = var; A.loss = c->ws.ray_loss;
     if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
-    k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());
-    if (d_loss) k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss);
+    if (d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
     CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
     account(c, stage, N * S, N, true, flags);
     return 0;
@@ -864,9 +894,9 @@ extern "C" int nsk_track_step(nsk_ctx* c, int stage, int N, const float* ro, con
     A.mode = 3; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
     A.thr = c->scal + 1; A.handle_dynamic = handle_dynamic; A.detach_var = detach_var; A.loss = c->ws.ray_loss;
     if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
-    k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());
-    if (d_loss) k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss);
+    if (d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
     CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
     account(c, stage, N * S, N, true, flags);
     return 0;
@@ -974,6 +1004,8 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
         float ss, bc2s; adam_consts(lr[grp], b1, b2, step, ss, bc2s);
         GridState& G = c->grid[lv];
         int n = (int)G.n;
+        static const char* an[4] = {"adam_grid_coarse", "adam_grid_middle", "adam_grid_fine", "adam_grid_color"};
+        ProfScope ps(c, an[lv]);
         k_adam<<<(n / 4 + 255) / 256, 256, 0, c->stream>>>(n, G.v, c->slab + G.g_off, G.m, G.s, G.mask, ss, bc2s, b1, b2, eps);
         c->touched[grp] = false;
     }
@@ -984,7 +1016,7 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
             DecState& D = c->dec[w];
             if (!D.trainable || !D.loaded) continue;
             int n4 = (D.n + 3) & ~3;
-            k_adam<<<(n4 / 4 + 255) / 256, 256, 0, c->stream>>>(n4, D.p, c->slab + D.g_off, D.m, D.s, nullptr, ss, bc2s, b1, b2, eps);
+            { ProfScope ps(c, "adam_decoder"); k_adam<<<(n4 / 4 + 255) / 256, 256, 0, c->stream>>>(n4, D.p, c->slab + D.g_off, D.m, D.s, nullptr, ss, bc2s, b1, b2, eps); }
             CHK(repack(c, w));
         }
         c->touched[NSK_GROUP_DECODERS] = false;
@@ -1035,6 +1067,38 @@ extern "C" int nsk_allreduce_grads(nsk_ctx* c, void* comm)
     const int ncclFloat32 = 7, ncclSum = 0;
     int r = fn(c->slab, c->slab, c->slab_n, ncclFloat32, ncclSum, comm, c->stream);
     if (r != 0) return fail("ncclAllReduce failed with %d", r);
+    return 0;
+}
+
+extern "C" int nsk_profile_begin(nsk_ctx* c)
+{
+    if (!c) return fail("null ctx");
+    for (auto& r : c->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    c->prof_recs.clear();
+    c->prof = true;
+    return 0;
+}
+
+extern "C" int nsk_profile_end(nsk_ctx* c, char* buf, size_t n)
+{
+    if (!c || !buf || n < 2) return fail("nsk_profile_end: bad argument");
+    c->prof = false;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<std::string> names; std::vector<double> tot; std::vector<int> cnt;
+    for (auto& r : c->prof_recs) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        size_t k = 0;
+        for (; k < names.size(); ++k) if (names[k] == r.name) break;
+        if (k == names.size()) { names.push_back(r.name); tot.push_back(0); cnt.push_back(0); }
+        tot[k] += ms; cnt[k] += 1;
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    c->prof_recs.clear();
+    std::string out;
+    for (size_t k = 0; k < names.size(); ++k) { char line[160]; snprintf(line, sizeof(line), "%s %d %.6f\n", names[k].c_str(), cnt[k], tot[k]); out += line; }
+    if (out.size() + 1 > n) return fail("nsk_profile_end: buffer too small (%zu needed)", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
 }
 

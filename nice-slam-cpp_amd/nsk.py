@@ -23,6 +23,7 @@ SYMBOLS = (
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
     "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
     "nsk_adam_reset", "nsk_zero_grads", "nsk_grad_slab", "nsk_allreduce_grads", "nsk_last_call_stats",
+    "nsk_profile_begin", "nsk_profile_end",
 )
 
 
@@ -81,13 +82,43 @@ class _CudaArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+def _ordered(fn):
+    """order the context stream against torch's current stream around a launching call"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(self, *a, **k):
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        same = cur == self.tstream
+        if not same:
+            self.tstream.wait_stream(cur)
+        try:
+            return fn(self, *a, **k)
+        finally:
+            if not same:
+                cur.wait_stream(self.tstream)
+    return wrap
+
+
 class Context:
     """one nsk_ctx (one GPU, one HIP stream)"""
 
     def __init__(self, device=0, stream=None):
+        """stream: a torch.cuda.Stream to launch on (default: a new one).  Every launching method orders the
+        context's stream after torch's current stream and the current stream after the launch, so results are
+        safe to consume with ordinary torch ops; run under `with torch.cuda.stream(ctx.tstream)` to avoid the
+        two event waits per call."""
+        import torch
         self.h = C.c_void_p()
-        _chk(lib().nsk_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self.h)))
-        self.device = device
+        self.device = int(device)
+        lib()
+        if torch.cuda.is_available():
+            self.tstream = stream if stream is not None else torch.cuda.Stream(self.device)
+            handle = C.c_void_p(self.tstream.cuda_stream)
+        else:
+            self.tstream, handle = None, None
+        _chk(lib().nsk_ctx_create(self.device, handle, C.byref(self.h)))
 
     def close(self):
         if self.h:
@@ -169,6 +200,7 @@ class Context:
     def _S(self, gt_depth):
         return getattr(self, "n_samples", 32) + (getattr(self, "n_surface", 16) if gt_depth is not None else 0)
 
+    @_ordered
     def render_forward(self, stage, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0, want_weights=True):
         import torch
         N = rays_o.shape[0]
@@ -179,6 +211,7 @@ class Context:
                                       C.c_float(gt_depth_max), _ptr(rgb), _ptr(depth), _ptr(var), _ptr(w)))
         return rgb, depth, var, w
 
+    @_ordered
     def eval_points(self, stage, pts):
         import torch
         M = pts.shape[0]
@@ -186,6 +219,7 @@ class Context:
         _chk(lib().nsk_eval_points(self.h, _stage(stage), M, _ptr(pts), _ptr(raw)))
         return raw
 
+    @_ordered
     def render_backward(self, stage, rays_o, rays_d, gt_depth, gt_depth_max, g_rgb, g_depth, g_var=None, flags=GRAD_GRIDS):
         import torch
         N = rays_o.shape[0]
@@ -197,6 +231,7 @@ class Context:
                                        _ptr(g_ro), _ptr(g_rd)))
         return g_ro, g_rd
 
+    @_ordered
     def map_step(self, stage, rays_o, rays_d, gt_depth, gt_color, gt_depth_max=-1.0, w_color=0.2, use_color=True,
                  flags=GRAD_GRIDS | GRAD_DECODERS, loss=None, outputs=None, g_rays=None):
         N = rays_o.shape[0]
@@ -206,6 +241,7 @@ class Context:
                                 C.c_float(gt_depth_max), C.c_float(w_color), int(use_color), C.c_uint(flags), _ptr(loss),
                                 _ptr(rgb), _ptr(depth), _ptr(var), _ptr(g_ro), _ptr(g_rd)))
 
+    @_ordered
     def track_step(self, stage, rays_o, rays_d, gt_depth, gt_color, gt_depth_max=-1.0, w_color=0.5, use_color=True,
                    handle_dynamic=True, detach_var=True, flags=GRAD_RAYS, loss=None, g_rays=None):
         N = rays_o.shape[0]
@@ -214,6 +250,7 @@ class Context:
                                   C.c_float(gt_depth_max), C.c_float(w_color), int(use_color), int(handle_dynamic),
                                   int(detach_var), C.c_uint(flags), _ptr(loss), _ptr(g_ro), _ptr(g_rd)))
 
+    @_ordered
     def loss_map(self, depth, rgb, gt_depth, gt_color, w_color, use_color):
         import torch
         N = depth.shape[0]
@@ -223,6 +260,7 @@ class Context:
                                 int(use_color), _ptr(g_d), _ptr(g_c), _ptr(loss)))
         return loss, g_d, g_c
 
+    @_ordered
     def loss_track(self, depth, rgb, var, gt_depth, gt_color, w_color, use_color, handle_dynamic, detach_var=True):
         import torch
         N = depth.shape[0]
@@ -235,6 +273,7 @@ class Context:
         return loss, g_d, g_c, g_v
 
     # -- rays / pose ------------------------------------------------------------------------------------------
+    @_ordered
     def rays_from_pixels(self, pix_i, pix_j, intr, c2w, mode=0):
         import torch
         n = pix_i.shape[0]
@@ -244,6 +283,7 @@ class Context:
                                         C.c_float(cy), _ptr(c2w), mode, _ptr(ro), _ptr(rd)))
         return ro, rd
 
+    @_ordered
     def rays_backward(self, pix_i, pix_j, intr, g_ro, g_rd, mode=0):
         import torch
         g = torch.empty(3, 4, device=g_ro.device)
@@ -252,36 +292,43 @@ class Context:
                                      C.c_float(cx), C.c_float(cy), mode, _ptr(g_ro), _ptr(g_rd), _ptr(g)))
         return g
 
+    @_ordered
     def camera_from_tensor(self, cam):
         import torch
         c2w = torch.empty(3, 4, device=cam.device)
         _chk(lib().nsk_camera_from_tensor(self.h, _ptr(cam), _ptr(c2w)))
         return c2w
 
+    @_ordered
     def camera_backward(self, cam, g_c2w):
         import torch
         g = torch.empty(7, device=cam.device)
         _chk(lib().nsk_camera_backward(self.h, _ptr(cam), _ptr(g_c2w), _ptr(g)))
         return g
 
+    @_ordered
     def inside_filter(self, rays_o, rays_d, gt_depth):
         import torch
         keep = torch.empty(rays_o.shape[0], dtype=torch.uint8, device=rays_o.device)
         _chk(lib().nsk_inside_filter(self.h, rays_o.shape[0], _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), _ptr(keep)))
         return keep.bool()
 
+    @_ordered
     def adam_vector(self, p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8):
         _chk(lib().nsk_adam_vector(self.h, p.numel(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_float(lr), C.c_float(b1),
                                    C.c_float(b2), C.c_float(eps), int(step)))
 
     # -- optimiser / multi-GPU ----------------------------------------------------------------------------------
+    @_ordered
     def adam_step(self, lr, b1=0.9, b2=0.999, eps=1e-8):
         arr = (C.c_float * 6)(*[float(x) for x in lr])
         _chk(lib().nsk_adam_step(self.h, arr, C.c_float(b1), C.c_float(b2), C.c_float(eps)))
 
+    @_ordered
     def adam_reset(self):
         _chk(lib().nsk_adam_reset(self.h))
 
+    @_ordered
     def zero_grads(self):
         _chk(lib().nsk_zero_grads(self.h))
 
@@ -291,6 +338,19 @@ class Context:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(lib().nsk_grad_slab(self.h, C.byref(p), C.byref(n)))
         return torch.as_tensor(_CudaArray(p.value, n.value), device="cuda:%d" % self.device)
+
+    def profile_begin(self):
+        _chk(lib().nsk_profile_begin(self.h))
+
+    def profile_end(self):
+        """{kernel name: (launches, total ms)} measured with HIP events on the context's stream"""
+        buf = C.create_string_buffer(8192)
+        _chk(lib().nsk_profile_end(self.h, buf, C.c_size_t(8192)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
 
     def last_call_stats(self):
         b, f, s = C.c_double(), C.c_double(), C.c_int()

@@ -25,6 +25,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #ifndef REAL
 #define REAL float
@@ -504,8 +507,23 @@ NSO_API int nso_render_backward(const nso_opts* o, const nso_grid* grids, const 
     dec_layout L[4]; for (int i = 0; i < 4; ++i) make_layout(i, &L[i]);
     if (o->n_samples + o->n_surface > MAX_S) return -1;
     if (gt_depth && gt_depth_max < 0) gt_depth_max = nso_depth_max(N, gt_depth);
-    pt_state* st = (pt_state*)malloc(sizeof(pt_state) * MAX_S);
     const int want_rays = g_rays_o != NULL || g_rays_d != NULL;
+    /* rays are independent; each thread accumulates parameter gradients privately, then the partials are summed
+     * (single-threaded when N is small so that the summation order is the plain ray order) */
+#pragma omp parallel if (N > 64)
+    {
+    pt_state* st = (pt_state*)malloc(sizeof(pt_state) * MAX_S);
+    real* tg[4] = { 0, 0, 0, 0 }; real* tp[4] = { 0, 0, 0, 0 };
+    int shared_acc = 1;
+#ifdef _OPENMP
+    shared_acc = omp_get_num_threads() == 1;
+#endif
+    for (int l = 0; l < 4; ++l) {
+        size_t ng = (size_t)grids[l].C * grids[l].Z * grids[l].Y * grids[l].X;
+        if (g_grids && g_grids[l]) tg[l] = shared_acc ? g_grids[l] : (real*)calloc(ng, sizeof(real));
+        if (g_P && g_P[l]) tp[l] = shared_acc ? g_P[l] : (real*)calloc(L[l].total, sizeof(real));
+    }
+#pragma omp for schedule(dynamic, 4)
     for (int n = 0; n < N; ++n) {
         const real* ro = rays_o + 3 * n; const real* rd = rays_d + 3 * n;
         real z[MAX_S], raw[MAX_S * 4], al[MAX_S], T[MAX_S], w[MAX_S], rgb[3], D, V;
@@ -556,10 +574,9 @@ NSO_API int nso_render_backward(const nso_opts* o, const nso_grid* grids, const 
                 if (wd == 3) { g_out[0] = g_col[0]; g_out[1] = g_col[1]; g_out[2] = g_col[2]; }
                 else g_out[0] = g_sigma;
                 real g_c[64];
-                dec_backward(&L[wd], P[wd], p, &st[s].act[wd], g_out, g_P ? g_P[wd] : NULL, g_c,
-                             want_rays ? g_p : NULL);
+                dec_backward(&L[wd], P[wd], p, &st[s].act[wd], g_out, tp[wd], g_c, want_rays ? g_p : NULL);
                 /* fine: only the first 32 features (grid_fine) carry gradient (MLP.cpp:81 NoGradGuard) */
-                tri_backward(&grids[wd], &st[s].tc[wd], g_c, g_grids ? g_grids[wd] : NULL, want_rays ? g_p : NULL);
+                tri_backward(&grids[wd], &st[s].tc[wd], g_c, tg[wd], want_rays ? g_p : NULL);
             }
             for (int k = 0; k < 3; ++k) { g_o[k] += g_p[k]; g_d[k] += g_p[k] * z[s]; }
         }
@@ -567,10 +584,18 @@ NSO_API int nso_render_backward(const nso_opts* o, const nso_grid* grids, const 
         if (g_rays_o) memcpy(g_rays_o + 3 * n, g_o, sizeof(g_o));
         if (g_rays_d) memcpy(g_rays_d + 3 * n, g_d, sizeof(g_d));
     }
+    if (!shared_acc) {
+#pragma omp critical
+        for (int l = 0; l < 4; ++l) {
+            size_t ng = (size_t)grids[l].C * grids[l].Z * grids[l].Y * grids[l].X;
+            if (tg[l]) { for (size_t i = 0; i < ng; ++i) g_grids[l][i] += tg[l][i]; free(tg[l]); }
+            if (tp[l]) { for (size_t i = 0; i < L[l].total; ++i) g_P[l][i] += tp[l][i]; free(tp[l]); }
+        }
+    }
     free(st);
+    }
     return 0;
 }
-
 
 /* Test aid (not in the reference): per-ray fragility = min |x| over every ReLU input on the ray (hidden
  * pre-activations of the decoders the stage uses, and sigma of in-bound samples in density mode).
@@ -768,4 +793,13 @@ NSO_API int nso_inside_filter(const real* bound, int N, const real* rays_o, cons
     int c = 0;
     for (int n = 0; n < N; ++n) { keep[n] = ray_box_far(bound, rays_o + 3 * n, rays_d + 3 * n) >= gt_depth[n]; c += keep[n]; }
     return c;
+}
+
+NSO_API int nso_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }

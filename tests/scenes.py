@@ -115,8 +115,8 @@ def make_rays(seed, n, bound, H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=33
     color = 0.5 + 0.5 * np.sin(hit * np.array([1.3, 2.1, 0.7]) + np.array([0.0, 1.0, 2.0]))
     zero = rng.random(ro.shape[0]) < zero_frac
     depth = np.where(zero, 0.0, depth)
-    return dict(rays_o=ro.astype(np.float32), rays_d=rd.astype(np.float32), gt_depth=depth.astype(np.float32),
-                gt_color=color.astype(np.float32), pix_i=np.concatenate(pi).astype(np.int32),
+    c32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return dict(rays_o=c32(ro), rays_d=c32(rd), gt_depth=c32(depth), gt_color=c32(color), pix_i=np.concatenate(pi).astype(np.int32),
                 pix_j=np.concatenate(pj).astype(np.int32), frame=np.concatenate(fr).astype(np.int32),
                 c2w=np.stack(cams).astype(np.float32), intr=(fx, fy, cx, cy), HW=(H, W))
 

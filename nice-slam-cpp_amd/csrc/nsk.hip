@@ -2,6 +2,7 @@
 // Built only for gfx950:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC nsk.hip -o libnsk.so
 #include "../../include/nsk.h"
 #include "nsk_device.h"
+#include "nsk_train.h"
 
 #include <dlfcn.h>
 #include <cstdarg>
@@ -249,6 +250,7 @@ struct Workspace {
     unsigned long long* masks[4] = {nullptr, nullptr, nullptr, nullptr};
     float* g_raw = nullptr; float* ray_loss = nullptr;
     float* tmp_rgb = nullptr; float* tmp_depth = nullptr; float* tmp_var = nullptr;
+    float* dec_slabs = nullptr;      // per-workgroup partial decoder gradients [num_cu][20920]
 };
 struct nsk_ctx {
     int device = 0;
@@ -305,9 +307,8 @@ static size_t bwd_lds_bytes(int w, bool train)
 {
     size_t scratch = 8 * 3840;
     if (!train) return bwd_img_floats(w) * 4 + scratch;
-    size_t npar4 = (nsk_dec_layout(w).total + 3) & ~3;
     size_t img = w == 2 ? 0 : fwd_img_floats(w);
-    return (img + npar4) * 4 + scratch;
+    return (img + PN_FLOATS + 8 * 832) * 4;
 }
 
 extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
@@ -338,7 +339,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     CHK(set_lds(k_decode_fwd<2>, fwd_img_floats(2) * 4)); CHK(set_lds(k_decode_fwd<3>, fwd_img_floats(3) * 4));
 #define SETB(W) \
     CHK(set_lds(k_decode_bwd<W, false, false>, bwd_lds_bytes(W, false))); CHK(set_lds(k_decode_bwd<W, false, true>, bwd_lds_bytes(W, false))); \
-    CHK(set_lds(k_decode_bwd<W, true, false>, bwd_lds_bytes(W, true))); CHK(set_lds(k_decode_bwd<W, true, true>, bwd_lds_bytes(W, true)));
+    CHK(set_lds(k_decode_bwd_train<W, false>, bwd_lds_bytes(W, true))); CHK(set_lds(k_decode_bwd_train<W, true>, bwd_lds_bytes(W, true)));
     SETB(0) SETB(1) SETB(2) SETB(3)
 #undef SETB
     CHK(set_lds(k_median_thr, 16384 * 4));
@@ -350,7 +351,7 @@ static void free_ws(Workspace& w)
 {
     hipFree(w.z); for (int i = 0; i < 3; ++i) hipFree(w.occ[i]); hipFree(w.rgb4);
     for (int i = 0; i < 4; ++i) hipFree(w.masks[i]);
-    hipFree(w.g_raw); hipFree(w.ray_loss); hipFree(w.tmp_rgb); hipFree(w.tmp_depth); hipFree(w.tmp_var);
+    hipFree(w.g_raw); hipFree(w.ray_loss); hipFree(w.tmp_rgb); hipFree(w.tmp_depth); hipFree(w.tmp_var); hipFree(w.dec_slabs);
     w = Workspace();
 }
 
@@ -619,6 +620,8 @@ static int ensure_ws(nsk_ctx* c, int N, int M)
     size_t n = (size_t)capN + 64;
     HIPCHK(hipMalloc(&w.ray_loss, n * 4));
     HIPCHK(hipMalloc(&w.tmp_rgb, n * 12)); HIPCHK(hipMalloc(&w.tmp_depth, n * 4)); HIPCHK(hipMalloc(&w.tmp_var, n * 4));
+    HIPCHK(hipMalloc(&w.dec_slabs, (size_t)c->num_cu * 20920 * 4));
+    HIPCHK(hipMemsetAsync(w.dec_slabs, 0, (size_t)c->num_cu * 20920 * 4, c->stream));
     w.capM = capM; w.capN = capN;
     return 0;
 }
@@ -665,7 +668,7 @@ static int launch_decode_fwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     A.masks = save_masks ? c->ws.masks[w] : nullptr;
     int ntasks = (M + 15) / 16;
     size_t lds = fwd_img_floats(w) * 4;
-    int maxwg = c->num_cu * (lds <= 80 * 1024 ? 2 : 1);
+    int maxwg = c->num_cu;        // persistent: one workgroup per CU balances the 16-sample tasks over SIMDs
     int grid = std::max(1, std::min((ntasks + 7) / 8, maxwg));
     static const char* names[4] = {"decode_fwd_coarse", "decode_fwd_middle", "decode_fwd_fine", "decode_fwd_color"};
     ProfScope ps(c, names[w]);
@@ -688,16 +691,17 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     A.masks = c->ws.masks[w];
     A.g_raw = c->ws.g_raw;
     A.g_rays_o = g_ro; A.g_rays_d = g_rd;
-    A.g_dec = c->slab + c->dec[w].g_off;
+    A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
     A.flags = flags;
     int ntasks = (M + 15) / 16;
     size_t lds = bwd_lds_bytes(w, train);
     int grid = std::max(1, std::min((ntasks + 7) / 8, c->num_cu));
     static const char* names[8] = {"decode_bwd_coarse", "decode_bwd_middle", "decode_bwd_fine", "decode_bwd_color",
                                    "decode_bwd_coarse_train", "decode_bwd_middle_train", "decode_bwd_fine_train", "decode_bwd_color_train"};
+    {
     ProfScope ps(c, names[w + (train ? 4 : 0)]);
 #define LB(W) \
-    if (train) { if (rays) k_decode_bwd<W, true, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd<W, true, false><<<grid, 512, lds, c->stream>>>(A); } \
+    if (train) { if (rays) k_decode_bwd_train<W, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd_train<W, false><<<grid, 512, lds, c->stream>>>(A); } \
     else { if (rays) k_decode_bwd<W, false, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd<W, false, false><<<grid, 512, lds, c->stream>>>(A); }
     switch (w) {
     case 0: LB(0) break;
@@ -706,7 +710,14 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     default: LB(3) break;
     }
 #undef LB
+    }
     HIPCHK(hipGetLastError());
+    if (train) {
+        int n = c->dec[w].n, n4 = (n + 3) & ~3;
+        ProfScope ps2(c, "dec_grad_reduce");
+        k_dec_grad_reduce<<<dim3((n + 255) / 256, 8), 256, 0, c->stream>>>(n, n4, grid, c->ws.dec_slabs, c->slab + c->dec[w].g_off);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 

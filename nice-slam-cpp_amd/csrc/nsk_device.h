@@ -236,6 +236,17 @@ __device__ __forceinline__ void gemm(const f4* __restrict__ img, int quad0, int 
     }
 }
 
+// [96 x 32] transposed e-part product as three 32-row slices (bounds the fragment registers in flight)
+__device__ __forceinline__ void gemm_e(const f4* __restrict__ img, int quad0, int lane, const f4 (&x)[2], f4 (&acc)[6])
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        f4 t[2] = {acc[2 * a], acc[2 * a + 1]};
+        gemm<2, 2>(img, quad0 + 4 * a, lane, x, t);
+        acc[2 * a] = t[0]; acc[2 * a + 1] = t[1];
+    }
+}
+
 // bias vector [32] in D layout: lane holds features 4g+i and 16+4g+i
 __device__ __forceinline__ void load_bias(const float* __restrict__ b, int g, f4 (&acc)[2])
 {
@@ -625,23 +636,41 @@ __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const
     float* wt = scratch + 16 * 36 + 128;                    // [16][8]
     *reinterpret_cast<f4*>(gct + j * 36 + 4 * g) = valid ? gc[0] : (f4)(0.f);
     *reinterpret_cast<f4*>(gct + j * 36 + 16 + 4 * g) = valid ? gc[1] : (f4)(0.f);
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        if ((c >> 1) == g) { vx[j * 8 + c] = T.vox[c]; wt[j * 8 + c] = valid ? T.w[c] : 0.f; }
-    lds_fence();
-    const int ch = lane & 31, sh = lane >> 5;
-#pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-        const int jj = 2 * it + sh;
-        const float v = gct[jj * 36 + ch];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float w = wt[jj * 8 + c];
-            const int vox = vx[jj * 8 + c];
-            const float add = w * v;
-            if (add != 0.f && (!G.mask || G.mask[vox])) atomicAdd(G.g + (size_t)vox * 32 + ch, add);
-        }
+    if (g == 0) {     // static indices only (a per-lane pick of two corners would index the register array dynamically)
+        *reinterpret_cast<int4*>(vx + j * 8) = make_int4(T.vox[0], T.vox[1], T.vox[2], T.vox[3]);
+        *reinterpret_cast<int4*>(vx + j * 8 + 4) = make_int4(T.vox[4], T.vox[5], T.vox[6], T.vox[7]);
+        *reinterpret_cast<f4*>(wt + j * 8) = valid ? (f4){T.w[0], T.w[1], T.w[2], T.w[3]} : (f4)(0.f);
+        *reinterpret_cast<f4*>(wt + j * 8 + 4) = valid ? (f4){T.w[4], T.w[5], T.w[6], T.w[7]} : (f4)(0.f);
     }
+    lds_fence();
+    // lanes 0-31 own corners 0-3, lanes 32-63 corners 4-7, of channel ch.  Samples of a tile are consecutive
+    // along a ray (sorted by depth), so runs of samples share a cell: their contributions are summed in
+    // registers and flushed once per run (fewer, still full-line, atomics).
+    const int ch = lane & 31, hf = lane >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int cur[4] = {0, 0, 0, 0};
+    int cur_cell = -1;
+    for (int jj = 0; jj < 16; ++jj) {
+        const int cell = __builtin_amdgcn_readfirstlane(vx[jj * 8]);
+        if (cell != cur_cell) {
+            if (cur_cell >= 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (acc[c] != 0.f && (!G.mask || G.mask[cur[c]])) atomicAdd(G.g + (size_t)cur[c] * 32 + ch, acc[c]);
+            }
+            cur_cell = cell;
+            const int4 v4 = *reinterpret_cast<const int4*>(vx + jj * 8 + 4 * hf);
+            cur[0] = v4.x; cur[1] = v4.y; cur[2] = v4.z; cur[3] = v4.w;
+            acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+        }
+        const float v = gct[jj * 36 + ch];
+        const f4 w4 = *reinterpret_cast<const f4*>(wt + jj * 8 + 4 * hf);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += w4[c] * v;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (acc[c] != 0.f && (!G.mask || G.mask[cur[c]])) atomicAdd(G.g + (size_t)cur[c] * 32 + ch, acc[c]);
     lds_fence();
 }
 
@@ -699,7 +728,7 @@ __device__ __forceinline__ void wg_add(float* __restrict__ acc, int base, int ld
                                        int lane, f4 d)
 {
     const int x = lane & 15, g = lane >> 4;
-    if (x < cols) {
+    if (x < cols && acc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int o = 16 * rt + 4 * g + i;
@@ -707,6 +736,11 @@ __device__ __forceinline__ void wg_add(float* __restrict__ acc, int base, int ld
         }
     }
 }
+#ifdef NSK_EXPERIMENT
+#define NSK_DBG(A, bit) (((A).flags >> (bit)) & 1u)
+#else
+#define NSK_DBG(A, bit) 0u
+#endif
 
 // one X chunk against both G row tiles
 __device__ __forceinline__ void wg_chunk(float* __restrict__ acc, int base, int ld, int col0, int rows, int cols,
@@ -734,7 +768,7 @@ __device__ __forceinline__ void wg_add_rowsum(float* __restrict__ acc, int base,
             f4 d = (f4)(0.f);
 #pragma unroll
             for (int i = 0; i < 4; ++i) d = mfma4(a[i], 1.0f, d);
-            if (r == 0) {
+            if (r == 0 && acc) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     int o = 16 * rt + 4 * sq + i;
@@ -795,6 +829,9 @@ __global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A)
                             : (XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO);
     float* tg = scratch;                  // [32][20]
     float* tx = scratch + 32 * TG_LD;     // [16][20]
+    float* const dacc_real = dacc;
+    if (NSK_DBG(A, 8)) dacc = nullptr;
+    const bool skip_wg = NSK_DBG(A, 10);
 
     const int ntasks = (A.M + 15) >> 4;
     for (int task = blockIdx.x * 8 + wave; task < ntasks; task += gridDim.x * 8) {
@@ -850,7 +887,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A)
                 for (int o = 0; o < OD; ++o) s += Wo[32 * o + 16 * r + 4 * g + i] * gout[o];
                 gh[r][i] = s;
             }
-        if constexpr (TRAIN) {   // d output_linear
+        if (TRAIN && !skip_wg) {   // d output_linear
             wg_zero_tg(tg, lane);
             lds_fence();
             if (g == 0) {
@@ -878,7 +915,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A)
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
-            if constexpr (TRAIN) {
+            if (TRAIN && !skip_wg) {
                 if constexpr (XYZ) {       // d fc[l] = g_h c^T, d fc_bias[l] = sum g_h
                     wg_put_quad(tg, lane, gh[0]);
                     wg_put_quad(tg + 16 * TG_LD, lane, gh[1]);
@@ -918,8 +955,8 @@ __global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A)
             }
             if constexpr (XYZ) {
                 if constexpr (NEED_E) {
-                    if (l == 3) gemm<6, 2>(bimg, MlpBwdImg::W3ET, lane, ga, ge);
-                    if (l == 0) gemm<6, 2>(bimg, MlpBwdImg::W0ET, lane, ga, ge);
+                    if (l == 3) gemm_e(bimg, MlpBwdImg::W3ET, lane, ga, ge);
+                    if (l == 0) gemm_e(bimg, MlpBwdImg::W0ET, lane, ga, ge);
                 }
                 if (l >= 1) {
                     f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
@@ -942,7 +979,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A)
         if constexpr (NEED_E) {
 #pragma unroll
             for (int q = 0; q < 6; ++q) ge[q] *= xcos[q];
-            if constexpr (TRAIN) {
+            if (TRAIN && !skip_wg) {
                 wg_zero_tg(tg, lane);
                 lds_fence();
                 if (g == 0) { tg[0 * TG_LD + j] = valid ? px : 0.f; tg[1 * TG_LD + j] = valid ? py : 0.f; tg[2 * TG_LD + j] = valid ? pz : 0.f; }
@@ -974,12 +1011,12 @@ __global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A)
                 }
             }
         }
-        if ((A.flags & 1u) && A.grid.g) scatter_tile(A.grid, T, gc, lane, valid, scratch);
+        if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) scatter_tile(A.grid, T, gc, lane, valid, scratch);
     }
     if constexpr (TRAIN) {
         __syncthreads();
         for (int i = threadIdx.x; i < NPAR; i += 512) {
-            float v = dacc[i];
+            float v = dacc_real[i];
             if (v != 0.f) atomicAdd(A.g_dec + i, v);
         }
     }

@@ -1,0 +1,385 @@
+// nsk_train.h -- backward of a TRAINABLE decoder: forward recompute, gradient chain, feature-gradient scatter and
+// all parameter gradients.
+//
+// Parameter gradients are contractions over samples, dW[o][x] = sum_s G[o][s] X[x][s].  A workgroup's 8 waves each
+// own one 16-sample tile per iteration; per layer they transpose their G (upstream) and X (layer input) tiles into
+// one shared LDS panel [rows][8 x 16 samples], and every 16x16 output tile of dW is then produced by ONE wave as a
+// K = 128 MFMA chain over the whole panel and kept in that wave's registers across all iterations.  No LDS or
+// global atomics are involved until the single flush at the end of the kernel (measured: ds_add_f32 accumulation
+// of per-wave partials cost 257 us of a 420 us kernel at 1000 rays; profiles/r01b_*).
+#pragma once
+#include "nsk_device.h"
+#include <type_traits>
+
+#define PN_LD 132                     // panel row stride in floats (128 samples + 4 pad)
+#define PN_GROWS 32                   // rows 0..31: G, rows 32..127: X
+#define PN_ROWS 128
+#define PN_FLOATS (PN_ROWS * PN_LD)   // 16896 floats = 67584 B
+
+// one phase = one (G, X) pair: RT row tiles of G, NC 16-row chunks of X, optional row sums (bias gradients)
+struct TrainPhase {
+    int RT, NC, rowsum;       // tiles = RT*NC (+ RT)
+    int slot0, nslots;        // this wave's accumulator slots [slot0, slot0+nslots)
+    int w_base, ld, col0;     // canonical destination of dW: w_base + o*ld + col0 + 16*chunk + x
+    int rows, cols_total;     // valid rows of G, valid columns over all chunks
+    int b_base;               // canonical destination of the row sums (bias), -1 if none
+};
+
+template <int WHICH>
+struct TrainPlan {
+    static constexpr bool XYZ = WHICH != 0;
+    static constexpr int CQ = WHICH == 2 ? 4 : 2;
+    static constexpr int OD = WHICH == 3 ? 4 : 1;
+    // phase ids
+    static constexpr int P_OUT = 0;
+    static constexpr int P_FC0 = 1;                 // P_FC0 + l (XYZ only)
+    static constexpr int P_W0 = 6;                  // P_W0 + l
+    static constexpr int P_W3H = 11;                // second X panel of layer 3 (h2 for MLP, h2 for coarse)
+    static constexpr int P_DB = 12;                 // embedding matrix B (XYZ only)
+    static constexpr int NPH = 13;
+    TrainPhase p[NPH];
+    int nslots;
+    constexpr TrainPlan() : p{}, nslots(0)
+    {
+        constexpr DecLayoutDev L = dec_layout_dev<WHICH>();
+        int s = 0;
+        auto set = [&](int id, int RT, int NC, int rowsum, int w_base, int ld, int col0, int rows, int cols_total, int b_base) {
+            int tiles = RT * NC + (rowsum ? RT : 0);
+            int ns = (tiles + 7) / 8;
+            p[id] = TrainPhase{RT, NC, rowsum, s, ns, w_base, ld, col0, rows, cols_total, b_base};
+            s += ns;
+        };
+        set(P_OUT, 1, 2, 1, L.oWo, 32, 0, OD, 32, L.obo);
+        if (XYZ) {
+            for (int l = 0; l < 5; ++l) set(P_FC0 + l, 2, CQ, 1, L.oFw[l], 16 * CQ, 0, 32, 16 * CQ, L.oFb[l]);
+            set(P_W0 + 0, 2, 6, 1, L.oW[0], NSK_E, 0, 32, NSK_E, L.ob[0]);
+            set(P_W0 + 1, 2, 2, 1, L.oW[1], 32, 0, 32, 32, L.ob[1]);
+            set(P_W0 + 2, 2, 2, 1, L.oW[2], 32, 0, 32, 32, L.ob[2]);
+            set(P_W0 + 3, 2, 6, 1, L.oW[3], 125, 0, 32, NSK_E, L.ob[3]);
+            set(P_W0 + 4, 2, 2, 1, L.oW[4], 32, 0, 32, 32, L.ob[4]);
+            set(P_W3H, 2, 2, 0, L.oW[3], 125, NSK_E, 32, 32, -1);
+            set(P_DB, 1, 6, 0, L.oB, NSK_E, 0, 3, NSK_E, -1);
+        } else {
+            set(P_W0 + 0, 2, 2, 1, L.oW[0], 32, 0, 32, 32, L.ob[0]);
+            set(P_W0 + 1, 2, 2, 1, L.oW[1], 32, 0, 32, 32, L.ob[1]);
+            set(P_W0 + 2, 2, 2, 1, L.oW[2], 32, 0, 32, 32, L.ob[2]);
+            set(P_W0 + 3, 2, 2, 1, L.oW[3], 64, 0, 32, 32, L.ob[3]);       // c part
+            set(P_W0 + 4, 2, 2, 1, L.oW[4], 32, 0, 32, 32, L.ob[4]);
+            set(P_W3H, 2, 2, 0, L.oW[3], 64, 32, 32, 32, -1);              // h2 part
+        }
+        nslots = s;
+    }
+};
+
+template <int WHICH>
+__host__ __device__ constexpr int plan_total() { return dec_layout_dev<WHICH>().total; }
+
+// g[i] += sum over workgroup slabs; grid (ceil(n/256), 8): each block sums 1/8 of the slabs for 256 parameters
+__global__ void k_dec_grad_reduce(int n, int n4, int nslabs, const float* __restrict__ slabs, float* __restrict__ g)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int per = (nslabs + gridDim.y - 1) / gridDim.y;
+    int s0 = blockIdx.y * per, s1 = min(nslabs, s0 + per);
+    float acc = 0.f;
+    for (int s = s0; s < s1; ++s) acc += slabs[(size_t)s * n4 + i];
+    if (acc != 0.f) atomicAdd(g + i, acc);
+}
+
+// transpose one D-layout quad (16 feature rows x this wave's 16 samples) into the panel at row `row0`
+__device__ __forceinline__ void pn_put(float* __restrict__ pn, int row0, int wave, int lane, f4 x)
+{
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pn[(row0 + 4 * g + i) * PN_LD + 16 * wave + j] = x[i];
+}
+
+// the tiles of one phase owned by this wave, accumulated over the panel's 128 samples
+template <int NSL>
+__device__ __forceinline__ void pn_tiles(const float* __restrict__ pn, int RT, int NC, int rowsum, int wave, int lane, f4* acc)
+{
+    const int r = lane & 15, sq = lane >> 4;
+    const int ntiles = RT * NC + (rowsum ? RT : 0);
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+        const int tile = 8 * k + wave;
+        if (tile < ntiles) {
+            const bool rs = tile >= RT * NC;
+            const int rt = rs ? tile - RT * NC : tile / NC;
+            const int ch = rs ? 0 : tile % NC;
+            const float* ga = pn + (16 * rt + r) * PN_LD + 4 * sq;
+            const float* xb = pn + (PN_GROWS + 16 * ch + r) * PN_LD + 4 * sq;
+            f4 d0 = acc[k], d1 = (f4)(0.f);
+#pragma unroll
+            for (int b = 0; b < 8; b += 2) {
+                f4 a0 = *reinterpret_cast<const f4*>(ga + 16 * b);
+                f4 a1 = *reinterpret_cast<const f4*>(ga + 16 * b + 16);
+                f4 x0 = (f4)(1.f), x1 = (f4)(1.f);
+                if (!rs) { x0 = *reinterpret_cast<const f4*>(xb + 16 * b); x1 = *reinterpret_cast<const f4*>(xb + 16 * b + 16); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { d0 = mfma4(a0[i], x0[i], d0); d1 = mfma4(a1[i], x1[i], d1); }
+            }
+            acc[k] = d0 + d1;
+        }
+    }
+}
+
+// store this wave's tiles of one phase into the workgroup's partial-gradient slab (canonical parameter layout).
+// Every parameter is covered by exactly one (wave, slot, lane, register), so plain stores suffice; the slabs of
+// all workgroups are summed by k_dec_grad_reduce (256 workgroups adding atomically into the same 15.9k addresses
+// cost 58 us of a 200 us kernel).
+template <int NSL>
+__device__ __forceinline__ void pn_flush(float* __restrict__ g_dec, const TrainPhase P, int wave, int lane, const f4* acc)
+{
+    const int x = lane & 15, g = lane >> 4;
+    const int ntiles = P.RT * P.NC + (P.rowsum ? P.RT : 0);
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+        const int tile = 8 * k + wave;
+        if (tile < ntiles) {
+            const bool rs = tile >= P.RT * P.NC;
+            const int rt = rs ? tile - P.RT * P.NC : tile / P.NC;
+            const int ch = rs ? 0 : tile % P.NC;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = 16 * rt + 4 * g + i;
+                const float v = acc[k][i];
+                if (o < P.rows) {
+                    if (rs) { if (x == 0) g_dec[P.b_base + o] = v; }
+                    else if (16 * ch + x < P.cols_total) g_dec[P.w_base + o * P.ld + P.col0 + 16 * ch + x] = v;
+                }
+            }
+        }
+    }
+}
+
+#ifdef NSK_EXPERIMENT
+#define NSK_BAR() do { if (!NSK_DBG(A, 12)) __syncthreads(); } while (0)
+#else
+#define NSK_BAR() __syncthreads()
+#endif
+
+template <int WHICH, bool RAYS>
+__global__ __launch_bounds__(512) void k_decode_bwd_train(DecArgs A)
+{
+    constexpr bool XYZ = WHICH != 0;
+    constexpr int CQ = WHICH == 2 ? 4 : 2;
+    constexpr int OD = WHICH == 3 ? 4 : 1;
+    constexpr bool FWD_LDS = WHICH != 2;            // fine: image + panel exceed 160 KiB, stream fragments from L2
+    typedef MlpFwdImg<CQ> FI;
+    typedef TrainPlan<WHICH> PL;
+    constexpr PL plan{};
+    constexpr int FWD_F = XYZ ? FI::TOTAL : CoarseFwdImg::TOTAL;
+    constexpr int IMG_F = FWD_LDS ? FWD_F : 0;
+    extern __shared__ __attribute__((aligned(16))) f4 smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    float* smf = reinterpret_cast<float*>(smem);
+    float* pn = smf + IMG_F;                        // shared panel
+    float* scratch = pn + PN_FLOATS + wave * 832;   // per-wave scatter scratch
+    for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.img[i];
+    __syncthreads();
+    const f4* fimg = FWD_LDS ? smem : A.img;
+    const float* fimgf = reinterpret_cast<const float*>(fimg);
+    const f4* bimg = A.bimg;                        // backward fragments stream from L2
+    const float* Bm = nullptr;
+    if constexpr (XYZ) Bm = fimgf + FI::P_BM;
+    const float* Wo = XYZ ? fimgf + FI::P_WO : fimgf + CoarseFwdImg::P_WO;
+
+    f4 acc[plan.nslots];
+#pragma unroll
+    for (int k = 0; k < plan.nslots; ++k) acc[k] = (f4)(0.f);
+
+    const int ntasks = (A.M + 15) >> 4;
+    const int per_iter = gridDim.x * 8;
+    const int iters = (ntasks + per_iter - 1) / per_iter;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" ::: "memory");
+        const int task = (it * gridDim.x + blockIdx.x) * 8 + wave;
+        const int m = task * 16 + j;
+        const bool valid = m < A.M;
+        const int mm = min(m, A.M - 1);
+        float px, py, pz, zz; int n;
+        sample_point(A, mm, px, py, pz, zz, n);
+        Tri T;
+        tri_setup(A.grid, A.bound, px, py, pz, T);
+        float gout[OD];
+        {
+            f4 gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+            if (!valid) gr = (f4)(0.f);
+            if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
+            else gout[0] = gr[3];
+        }
+        Act<CQ> C;
+        ActC CC;
+        f4 xcos[6];
+        unsigned long long mask;
+        if constexpr (XYZ) {
+            tri_gather(A.grid, T, g, C.xc[0], C.xc[1]);
+            if constexpr (WHICH == 2) {
+                Tri Tm;
+                tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
+                tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
+            }
+            embed<false>(Bm, g, px, py, pz, C.xe, xcos);     // cos is recomputed after the chain (24 fewer live registers)
+            mlp_forward<CQ>(fimg, lane, C);
+            mask = C.mask;
+        } else {
+            tri_gather(A.grid, T, g, CC.xc[0], CC.xc[1]);
+            coarse_forward(fimg, lane, CC);
+            mask = CC.mask;
+        }
+        f4 gh[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < OD; ++o) s += Wo[32 * o + 16 * r + 4 * g + i] * gout[o];
+                gh[r][i] = s;
+            }
+        // ---- phase OUT: G = g_out (rows >= OD zero), X = h4 ------------------------------------------------
+        {
+            f4 go;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) go[i] = (4 * g + i) < OD ? gout[(4 * g + i) < OD ? (4 * g + i) : 0] : 0.f;
+            pn_put(pn, 0, wave, lane, go);
+            const f4* h4 = XYZ ? C.h[4] : CC.h[4];
+            pn_put(pn, PN_GROWS, wave, lane, h4[0]);
+            pn_put(pn, PN_GROWS + 16, wave, lane, h4[1]);
+            NSK_BAR();
+            constexpr TrainPhase P = plan.p[PL::P_OUT];
+            pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+            NSK_BAR();
+        }
+        f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
+        f4 ge[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
+        auto layer = [&](auto LC) {
+            constexpr int l = decltype(LC)::value;
+            if constexpr (XYZ) {
+                gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);                 // g_c += fc[l]^T g_h
+                // ---- phase FC_l: G = g_h, X = c ------------------------------------------------------------
+                pn_put(pn, 0, wave, lane, gh[0]);
+                pn_put(pn, 16, wave, lane, gh[1]);
+#pragma unroll
+                for (int q = 0; q < CQ; ++q) pn_put(pn, PN_GROWS + 16 * q, wave, lane, C.xc[q]);
+                NSK_BAR();
+                constexpr TrainPhase P = plan.p[PL::P_FC0 + l];
+                pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                NSK_BAR();
+            }
+            f4 ga[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
+            // ---- phase W_l: G = g_a, X = layer input ----------------------------------------------------------
+            {
+                pn_put(pn, 0, wave, lane, ga[0]);
+                pn_put(pn, 16, wave, lane, ga[1]);
+                if constexpr (XYZ) {
+                    if constexpr (l == 0 || l == 3) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) pn_put(pn, PN_GROWS + 16 * q, wave, lane, C.xe[q]);
+                    } else {
+                        pn_put(pn, PN_GROWS, wave, lane, C.h[l - 1][0]);
+                        pn_put(pn, PN_GROWS + 16, wave, lane, C.h[l - 1][1]);
+                    }
+                } else {
+                    if constexpr (l == 0 || l == 3) { pn_put(pn, PN_GROWS, wave, lane, CC.xc[0]); pn_put(pn, PN_GROWS + 16, wave, lane, CC.xc[1]); }
+                    else { pn_put(pn, PN_GROWS, wave, lane, CC.h[l - 1][0]); pn_put(pn, PN_GROWS + 16, wave, lane, CC.h[l - 1][1]); }
+                }
+                NSK_BAR();
+                constexpr TrainPhase P = plan.p[PL::P_W0 + l];
+                pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                NSK_BAR();
+                if constexpr (l == 3) {        // second input panel of layer 3: h2 (G panel unchanged)
+                    const f4* h2 = XYZ ? C.h[2] : CC.h[2];
+                    pn_put(pn, PN_GROWS, wave, lane, h2[0]);
+                    pn_put(pn, PN_GROWS + 16, wave, lane, h2[1]);
+                    NSK_BAR();
+                    constexpr TrainPhase P2 = plan.p[PL::P_W3H];
+                    pn_tiles<P2.nslots>(pn, P2.RT, P2.NC, P2.rowsum, wave, lane, acc + P2.slot0);
+                    NSK_BAR();
+                }
+            }
+            if constexpr (XYZ) {
+                if constexpr (l == 3) gemm_e(bimg, MlpBwdImg::W3ET, lane, ga, ge);
+                if constexpr (l == 0) gemm_e(bimg, MlpBwdImg::W0ET, lane, ga, ge);
+                if constexpr (l >= 1) {
+                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
+                    gemm<2, 2>(bimg, MlpBwdImg::WT(l), lane, ga, ghn);
+                    gh[0] = ghn[0]; gh[1] = ghn[1];
+                }
+            } else {
+                if constexpr (l == 3) gemm<2, 2>(bimg, CoarseBwdImg::W3CT, lane, ga, gc);
+                if constexpr (l == 0) gemm<2, 2>(bimg, CoarseBwdImg::W0T, lane, ga, gc);
+                else {
+                    constexpr int q0 = l == 1 ? CoarseBwdImg::W1T : (l == 2 ? CoarseBwdImg::W2T : (l == 3 ? CoarseBwdImg::W3HT : CoarseBwdImg::W4T));
+                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
+                    gemm<2, 2>(bimg, q0, lane, ga, ghn);
+                    gh[0] = ghn[0]; gh[1] = ghn[1];
+                }
+            }
+        };
+        layer(std::integral_constant<int, 4>{});
+        layer(std::integral_constant<int, 3>{});
+        layer(std::integral_constant<int, 2>{});
+        layer(std::integral_constant<int, 1>{});
+        layer(std::integral_constant<int, 0>{});
+        float gp[3] = {0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));     // opaque: forces the recomputation below instead of keeping T / cos live
+        tri_setup(A.grid, A.bound, px, py, pz, T);
+        if constexpr (XYZ) {
+            { f4 e2[6]; embed<true>(Bm, g, px, py, pz, e2, xcos); }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ge[q] *= xcos[q];
+            // ---- phase DB: G = p (3 rows), X = g_s ----------------------------------------------------------
+            {
+                f4 pq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
+                pn_put(pn, 0, wave, lane, pq);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) pn_put(pn, PN_GROWS + 16 * q, wave, lane, ge[q]);
+                NSK_BAR();
+                constexpr TrainPhase P = plan.p[PL::P_DB];
+                pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                NSK_BAR();
+            }
+            if constexpr (RAYS) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    f4 b0 = *reinterpret_cast<const f4*>(Bm + 16 * q + 4 * g);
+                    f4 b1 = *reinterpret_cast<const f4*>(Bm + 96 + 16 * q + 4 * g);
+                    f4 b2 = *reinterpret_cast<const f4*>(Bm + 192 + 16 * q + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { gp[0] += ge[q][i] * b0[i]; gp[1] += ge[q][i] * b1[i]; gp[2] += ge[q][i] * b2[i]; }
+                }
+            }
+        }
+        if constexpr (RAYS) {
+            tri_grad_p(A.grid, T, g, gc, gp);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gp[k] += __shfl_xor(gp[k], 16); gp[k] += __shfl_xor(gp[k], 32); }
+            if (g == 0 && valid && A.g_rays_o) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    atomicAdd(A.g_rays_o + 3 * n + k, gp[k]);
+                    atomicAdd(A.g_rays_d + 3 * n + k, gp[k] * zz);
+                }
+            }
+        }
+        if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) scatter_tile(A.grid, T, gc, lane, valid, scratch);
+    }
+    if (NSK_DBG(A, 11)) return;
+    // ---- single flush of this wave's output tiles -------------------------------------------------------------
+    float* slab = A.g_dec + (size_t)blockIdx.x * ((plan_total<WHICH>() + 3) & ~3);
+    pn_flush<plan.p[PL::P_OUT].nslots>(slab, plan.p[PL::P_OUT], wave, lane, acc + plan.p[PL::P_OUT].slot0);
+#define NSK_FLUSH(ID) if constexpr (plan.p[ID].nslots > 0) pn_flush<plan.p[ID].nslots>(slab, plan.p[ID], wave, lane, acc + plan.p[ID].slot0);
+    NSK_FLUSH(1) NSK_FLUSH(2) NSK_FLUSH(3) NSK_FLUSH(4) NSK_FLUSH(5) NSK_FLUSH(6) NSK_FLUSH(7) NSK_FLUSH(8) NSK_FLUSH(9)
+    NSK_FLUSH(10) NSK_FLUSH(11) NSK_FLUSH(12)
+#undef NSK_FLUSH
+}

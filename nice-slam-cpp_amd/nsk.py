@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "csrc", "libnsk.so")
+_LIB_PATH = os.environ.get("NSK_LIB", os.path.join(_HERE, "csrc", "libnsk.so"))
 
 STAGES = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 LEVELS = ("coarse", "middle", "fine", "color")

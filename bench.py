@@ -161,6 +161,11 @@ def main():
     S = 48
     M = N * S
     per_kernel = {k: {"launches": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in prof.items()}
+    # merged launches: all decoders of the stage run as workgroup roles of one kernel
+    MAC["decode_fwd_multi"] = MAC["decode_fwd_middle"] + MAC["decode_fwd_fine"] + (MAC["decode_fwd_color"] if args.stage == "color" else 0)
+    BYTES["decode_fwd_multi"] = BYTES["decode_fwd_middle"] + BYTES["decode_fwd_fine"] + (BYTES["decode_fwd_color"] if args.stage == "color" else 0)
+    MAC["decode_bwd_multi"] = MAC["decode_bwd_middle"] + MAC["decode_bwd_fine"] + (MAC["decode_bwd_color_train"] if args.stage == "color" else 0)
+    BYTES["decode_bwd_multi"] = BYTES["decode_bwd_middle"] + BYTES["decode_bwd_fine"] + (BYTES["decode_bwd_color_train"] if args.stage == "color" else 0)
     dom = max((k for k in prof if k.startswith("decode")), key=lambda k: prof[k][1])
     dom_s = prof[dom][1] / prof[dom][0] * 1e-3
     flops = 2.0 * MAC[dom] * M

@@ -55,6 +55,43 @@ __global__ void k_adam(int n, float* __restrict__ p, float* __restrict__ g, floa
     *g4 = (f4)(0.f);
 }
 
+struct AdamSeg { float* p; float* g; float* m; float* v; const uint8_t* mask; int n; float step_size, bc2s; int blk_end; };
+struct AdamArgs { AdamSeg s[8]; int n; float b1, b2, eps; };
+// all parameter groups of one optimiser step in one launch (3 grid levels + trainable decoders)
+__global__ void k_adam_multi(AdamArgs A)
+{
+    int r = 0;
+    while (r < A.n - 1 && (int)blockIdx.x >= A.s[r].blk_end) ++r;
+    const AdamSeg& S = A.s[r];
+    const int b0 = r == 0 ? 0 : A.s[r - 1].blk_end;
+    const int i = (blockIdx.x - b0) * blockDim.x + threadIdx.x;
+    if (4 * i >= S.n) return;
+    f4* g4 = reinterpret_cast<f4*>(S.g) + i;
+    if (S.mask && !S.mask[i >> 3]) { *g4 = (f4)(0.f); return; }
+    f4 gg = *g4, pp = reinterpret_cast<f4*>(S.p)[i], mm = reinterpret_cast<f4*>(S.m)[i], vv = reinterpret_cast<f4*>(S.v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mm[k] = A.b1 * mm[k] + (1.f - A.b1) * gg[k];
+        vv[k] = A.b2 * vv[k] + (1.f - A.b2) * gg[k] * gg[k];
+        float denom = sqrtf(vv[k]) / S.bc2s + A.eps;
+        pp[k] -= S.step_size * (mm[k] / denom);
+    }
+    reinterpret_cast<f4*>(S.p)[i] = pp; reinterpret_cast<f4*>(S.m)[i] = mm; reinterpret_cast<f4*>(S.v)[i] = vv;
+    *g4 = (f4)(0.f);
+}
+
+struct PackSeg { float* img; const int* idx; const float* P; int n; int blk_end; };
+struct PackArgs { PackSeg s[8]; int n; };
+__global__ void k_pack_multi(PackArgs A)
+{
+    int r = 0;
+    while (r < A.n - 1 && (int)blockIdx.x >= A.s[r].blk_end) ++r;
+    const PackSeg& S = A.s[r];
+    const int b0 = r == 0 ? 0 : A.s[r - 1].blk_end;
+    const int i = (blockIdx.x - b0) * blockDim.x + threadIdx.x;
+    if (i < S.n) { int k = S.idx[i]; S.img[i] = k >= 0 ? S.P[k] : 0.f; }
+}
+
 __global__ void k_adam_scalar(int n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                               float* __restrict__ v, float step_size, float bc2s, float b1, float b2, float eps)
 {
@@ -343,6 +380,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     SETB(0) SETB(1) SETB(2) SETB(3)
 #undef SETB
     CHK(set_lds(k_median_thr, 16384 * 4));
+    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
     *out = c;
     return 0;
 }
@@ -721,6 +759,44 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     return 0;
 }
 
+// split num_cu workgroups over roles in proportion to their cost per task (every role gets at least one)
+static void split_wgs(int num_cu, int ntasks, int n, const int* cost, int* wg_end, int waves = 8)
+{
+    int cap = std::max(1, (ntasks + waves - 1) / waves), tot = 0, used = 0;
+    for (int r = 0; r < n; ++r) tot += cost[r];
+    for (int r = 0; r < n; ++r) {
+        int k = std::max(1, (int)((double)num_cu * cost[r] / tot));
+        k = std::min(k, cap);
+        used += k;
+        wg_end[r] = used;
+    }
+}
+
+// all decoders of the stage in ONE launch (workgroup roles), or a plain launch when the stage has one decoder
+static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const float* ro, const float* rd, bool save_masks)
+{
+    int n = 0;
+    for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) ++n;
+    if (n == 1) return launch_decode_fwd(c, STAGE_DEC[stage][0], M, S, ro, rd, nullptr, save_masks);
+    static const int fcost[4] = {96, 240, 320, 240};
+    MultiArgs MA;
+    memset(&MA, 0, sizeof(MA));
+    int cost[3]; size_t lds = 0;
+    for (int r = 0; r < n; ++r) {
+        int w = STAGE_DEC[stage][r];
+        fill_args(c, MA.a[r], w, M, S, ro, rd, nullptr);
+        MA.a[r].masks = save_masks ? c->ws.masks[w] : nullptr;
+        MA.which[r] = w; cost[r] = fcost[w];
+        lds = std::max(lds, fwd_img_floats(w) * 4);
+    }
+    MA.n = n;
+    split_wgs(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end, 8);
+    ProfScope ps(c, "decode_fwd_multi");
+    k_decode_fwd_multi<<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // algorithmic bytes / flops per sample
 static void account(nsk_ctx* c, int stage, int M, int N, bool bwd, unsigned flags)
 {
@@ -750,11 +826,7 @@ static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, co
     k_sample<<<(N + 3) / 4, 256, 0, c->stream>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, c->ws.z);
     }
     HIPCHK(hipGetLastError());
-    for (int q = 0; q < 3; ++q) {
-        int w = STAGE_DEC[stage][q];
-        if (w < 0) break;
-        CHK(launch_decode_fwd(c, w, M, S, ro, rd, nullptr, save_masks));
-    }
+    CHK(launch_decode_fwd_stage(c, stage, M, S, ro, rd, save_masks));
     return 0;
 }
 
@@ -816,19 +888,57 @@ extern "C" int nsk_eval_points(nsk_ctx* c, int stage, int M, const float* pts, f
     return 0;
 }
 
-// decoders' backward after k_composite wrote g_raw
+// decoders' backward after k_composite wrote g_raw: ONE launch for every decoder of the stage that needs it
 static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, unsigned flags, float* g_ro, float* g_rd)
 {
     const bool rays = (flags & NSK_GRAD_RAYS) != 0;
+    const bool grids = (flags & NSK_GRAD_GRIDS) != 0;
+    const int M = N * S;
+    MultiArgs MA;
+    memset(&MA, 0, sizeof(MA));
+    int n = 0, cost[3], train_role = -1; size_t lds = 0;
     for (int q = 2; q >= 0; --q) {
         int w = STAGE_DEC[stage][q];
         if (w < 0) continue;
         bool train = (flags & NSK_GRAD_DECODERS) && c->dec[w].trainable;
-        bool grids = (flags & NSK_GRAD_GRIDS) != 0;
         if (!train && !grids && !rays) continue;
-        CHK(launch_decode_bwd(c, w, N * S, S, ro, rd, train, rays, flags, g_ro, g_rd));
+        DecArgs& A = MA.a[n];
+        fill_args(c, A, w, M, S, ro, rd, nullptr);
+        A.grid = grid_dev(c, w, grids);
+        A.masks = c->ws.masks[w];
+        A.g_raw = c->ws.g_raw;
+        A.g_rays_o = g_ro; A.g_rays_d = g_rd;
+        A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
+        A.flags = flags;
+        MA.which[n] = w; MA.train[n] = train ? 1 : 0;
+        cost[n] = train ? 1000 : 120;      // frozen roles are bound by the chip-wide atomic rate, not by their CU count
+        lds = std::max(lds, bwd_lds_bytes(w, train));
+        if (train) train_role = train_role == -1 ? n : -2;     // -2: more than one trainable decoder -> separate launches below
         if (train) c->touched[NSK_GROUP_DECODERS] = true;
         if (grids) c->touched[NSK_GROUP_COARSE + w] = true;
+        ++n;
+    }
+    if (n == 0) return 0;
+    if (train_role == -2) {      // rare configuration (several trainable decoders share one slab buffer): one launch each
+        for (int r = 0; r < n; ++r)
+            CHK(launch_decode_bwd(c, MA.which[r], M, S, ro, rd, MA.train[r] != 0, rays, flags, g_ro, g_rd));
+        return 0;
+    }
+    MA.n = n;
+    split_wgs(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end);
+    {
+        ProfScope ps(c, "decode_bwd_multi");
+        if (rays) k_decode_bwd_multi<true><<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
+        else k_decode_bwd_multi<false><<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
+    }
+    HIPCHK(hipGetLastError());
+    if (train_role >= 0) {
+        int w = MA.which[train_role];
+        int nb = MA.wg_end[train_role] - (train_role == 0 ? 0 : MA.wg_end[train_role - 1]);
+        int np = c->dec[w].n, n4 = (np + 3) & ~3;
+        ProfScope ps2(c, "dec_grad_reduce");
+        k_dec_grad_reduce<<<dim3((np + 255) / 256, 8), 256, 0, c->stream>>>(np, n4, nb, c->ws.dec_slabs, c->slab + c->dec[w].g_off);
+        HIPCHK(hipGetLastError());
     }
     return 0;
 }
@@ -1008,30 +1118,40 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
 {
     if (!c || !lr) return fail("nsk_adam_step: null argument");
     HIPCHK(hipSetDevice(c->device));
+    AdamArgs AA; memset(&AA, 0, sizeof(AA));
+    PackArgs PA; memset(&PA, 0, sizeof(PA));
+    AA.b1 = b1; AA.b2 = b2; AA.eps = eps;
+    int blocks = 0, pblocks = 0;
     for (int lv = 0; lv < 4; ++lv) {
         int grp = NSK_GROUP_COARSE + lv;
         if (!c->touched[grp] || !c->grid[lv].n) continue;
         int step = ++c->adam_step[grp];
-        float ss, bc2s; adam_consts(lr[grp], b1, b2, step, ss, bc2s);
         GridState& G = c->grid[lv];
-        int n = (int)G.n;
-        static const char* an[4] = {"adam_grid_coarse", "adam_grid_middle", "adam_grid_fine", "adam_grid_color"};
-        ProfScope ps(c, an[lv]);
-        k_adam<<<(n / 4 + 255) / 256, 256, 0, c->stream>>>(n, G.v, c->slab + G.g_off, G.m, G.s, G.mask, ss, bc2s, b1, b2, eps);
+        AdamSeg& S = AA.s[AA.n++];
+        adam_consts(lr[grp], b1, b2, step, S.step_size, S.bc2s);
+        S.p = G.v; S.g = c->slab + G.g_off; S.m = G.m; S.v = G.s; S.mask = G.mask; S.n = (int)G.n;
+        blocks += ((int)G.n / 4 + 255) / 256; S.blk_end = blocks;
         c->touched[grp] = false;
     }
     if (c->touched[NSK_GROUP_DECODERS]) {
         int step = ++c->adam_step[NSK_GROUP_DECODERS];
-        float ss, bc2s; adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, ss, bc2s);
         for (int w = 0; w < 4; ++w) {
             DecState& D = c->dec[w];
             if (!D.trainable || !D.loaded) continue;
             int n4 = (D.n + 3) & ~3;
-            { ProfScope ps(c, "adam_decoder"); k_adam<<<(n4 / 4 + 255) / 256, 256, 0, c->stream>>>(n4, D.p, c->slab + D.g_off, D.m, D.s, nullptr, ss, bc2s, b1, b2, eps); }
-            CHK(repack(c, w));
+            AdamSeg& S = AA.s[AA.n++];
+            adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, S.step_size, S.bc2s);
+            S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.mask = nullptr; S.n = n4;
+            blocks += (n4 / 4 + 255) / 256; S.blk_end = blocks;
+            PackSeg& P1 = PA.s[PA.n++];
+            P1.img = D.fimg; P1.idx = D.fidx; P1.P = D.p; P1.n = D.fimg_n; pblocks += (D.fimg_n + 255) / 256; P1.blk_end = pblocks;
+            PackSeg& P2 = PA.s[PA.n++];
+            P2.img = D.bimg; P2.idx = D.bidx; P2.P = D.p; P2.n = D.bimg_n; pblocks += (D.bimg_n + 255) / 256; P2.blk_end = pblocks;
         }
         c->touched[NSK_GROUP_DECODERS] = false;
     }
+    if (AA.n) { ProfScope ps(c, "adam_multi"); k_adam_multi<<<blocks, 256, 0, c->stream>>>(AA); }
+    if (PA.n) { ProfScope ps(c, "pack_images"); k_pack_multi<<<pblocks, 256, 0, c->stream>>>(PA); }
     HIPCHK(hipGetLastError());
     return 0;
 }

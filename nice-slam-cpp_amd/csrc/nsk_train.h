@@ -160,7 +160,7 @@ __device__ __forceinline__ void pn_flush(float* __restrict__ g_dec, const TrainP
 #endif
 
 template <int WHICH, bool RAYS>
-__global__ __launch_bounds__(512) void k_decode_bwd_train(DecArgs A)
+__device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid, int nb)
 {
     constexpr bool XYZ = WHICH != 0;
     constexpr int CQ = WHICH == 2 ? 4 : 2;
@@ -190,11 +190,11 @@ __global__ __launch_bounds__(512) void k_decode_bwd_train(DecArgs A)
     for (int k = 0; k < plan.nslots; ++k) acc[k] = (f4)(0.f);
 
     const int ntasks = (A.M + 15) >> 4;
-    const int per_iter = gridDim.x * 8;
+    const int per_iter = nb * 8;
     const int iters = (ntasks + per_iter - 1) / per_iter;
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
-        const int task = (it * gridDim.x + blockIdx.x) * 8 + wave;
+        const int task = (it * nb + bid) * 8 + wave;
         const int m = task * 16 + j;
         const bool valid = m < A.M;
         const int mm = min(m, A.M - 1);
@@ -376,10 +376,35 @@ __global__ __launch_bounds__(512) void k_decode_bwd_train(DecArgs A)
     }
     if (NSK_DBG(A, 11)) return;
     // ---- single flush of this wave's output tiles -------------------------------------------------------------
-    float* slab = A.g_dec + (size_t)blockIdx.x * ((plan_total<WHICH>() + 3) & ~3);
+    float* slab = A.g_dec + (size_t)bid * ((plan_total<WHICH>() + 3) & ~3);
     pn_flush<plan.p[PL::P_OUT].nslots>(slab, plan.p[PL::P_OUT], wave, lane, acc + plan.p[PL::P_OUT].slot0);
 #define NSK_FLUSH(ID) if constexpr (plan.p[ID].nslots > 0) pn_flush<plan.p[ID].nslots>(slab, plan.p[ID], wave, lane, acc + plan.p[ID].slot0);
     NSK_FLUSH(1) NSK_FLUSH(2) NSK_FLUSH(3) NSK_FLUSH(4) NSK_FLUSH(5) NSK_FLUSH(6) NSK_FLUSH(7) NSK_FLUSH(8) NSK_FLUSH(9)
     NSK_FLUSH(10) NSK_FLUSH(11) NSK_FLUSH(12)
 #undef NSK_FLUSH
+}
+
+template <int WHICH, bool RAYS>
+__global__ __launch_bounds__(512) void k_decode_bwd_train(DecArgs A) { decode_bwd_train_body<WHICH, RAYS>(A, blockIdx.x, gridDim.x); }
+
+// one launch for the backward of all decoders of a stage (roles as in k_decode_fwd_multi; train[r] selects the
+// trainable-decoder body, whose workgroups synchronise only among themselves)
+template <bool RAYS>
+__global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
+{
+    int r = 0;
+    while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
+    const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];
+    const int bid = blockIdx.x - b0, nb = MA.wg_end[r] - b0;
+    const int sel = MA.which[r] * 2 + (MA.train[r] ? 1 : 0);
+    switch (sel) {
+    case 0: decode_bwd_body<0, false, RAYS>(MA.a[r], bid, nb); break;
+    case 1: decode_bwd_train_body<0, RAYS>(MA.a[r], bid, nb); break;
+    case 2: decode_bwd_body<1, false, RAYS>(MA.a[r], bid, nb); break;
+    case 3: decode_bwd_train_body<1, RAYS>(MA.a[r], bid, nb); break;
+    case 4: decode_bwd_body<2, false, RAYS>(MA.a[r], bid, nb); break;
+    case 5: decode_bwd_train_body<2, RAYS>(MA.a[r], bid, nb); break;
+    case 6: decode_bwd_body<3, false, RAYS>(MA.a[r], bid, nb); break;
+    default: decode_bwd_train_body<3, RAYS>(MA.a[r], bid, nb); break;
+    }
 }

@@ -111,11 +111,11 @@ def main():
     dev = torch.device("cuda", local)
     cu = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev).contiguous()
     batches = []
+    import nice_slam_cpp_amd.dist as nd
     for r in pool:
-        gmax = torch.tensor([float(r["gt_depth"].max())], device=dev)
-        if dist is not None:
-            dist.all_reduce(gmax, op=dist.ReduceOp.MAX)          # batch-global max(gt_depth) (Renderer.cpp:76,93)
-        batches.append((cu(r["rays_o"]), cu(r["rays_d"]), cu(r["gt_depth"]), cu(r["gt_color"]), float(gmax)))
+        gd = cu(r["gt_depth"])
+        gmax = nd.global_depth_max(gd)                           # batch-global max(gt_depth) (Renderer.cpp:76,93)
+        batches.append((cu(r["rays_o"]), cu(r["rays_d"]), gd, cu(r["gt_color"]), gmax))
     loss = torch.zeros(1, device=dev)
     flags = pkg.nsk.GRAD_GRIDS | pkg.nsk.GRAD_DECODERS
 
@@ -125,8 +125,7 @@ def main():
         def step(i):
             ro, rd, gd, gc, gmax = batches[i % len(batches)]
             ctx.map_step(args.stage, ro, rd, gd, gc, gmax, w_color, True, flags=flags, loss=loss)
-            if dist is not None:
-                dist.all_reduce(slab)                            # the one exchange of the path
+            nd.allreduce_grads(slab)                             # the one exchange of the path (no-op at N=1)
             ctx.adam_step(lr)
 
         for i in range(args.warmup):

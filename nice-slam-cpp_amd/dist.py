@@ -1,0 +1,52 @@
+"""Multi-GPU mapping: rays shard across ranks, grids / decoders / Adam state are replicated, and each mapping step
+needs exactly ONE all-reduce (sum, fp32) of the gradient slab.  `torch.distributed` is the
+transport: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+
+The only couplings that break naive ray sharding are batch-global statistics inside the renderer:
+max(gt_depth) (reference src/Renderer.cpp:76,93) -> all-reduced (max) here and passed to the kernels as
+`gt_depth_max`; the Tracker's median (src/Tracker.cpp:70) -> tracking stays on one rank (200 rays)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """contiguous shard [lo, hi) of n rays for `rank`; shards differ by at most one ray"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_depth_max(gt_depth, group=None):
+    """max(gt_depth) over the WHOLE batch although each rank only holds a shard"""
+    m = gt_depth.max().reshape(1).clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    return float(m)
+
+
+def allreduce_grads(slab, group=None):
+    """the one exchange of the path: sum the gradient slab (grids + decoders + loss scalar) over ranks, in place"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=group)
+    return slab
+
+
+class ShardedMapper:
+    """One mapping iteration on a ray shard.  `backend` is an nsk Context (or any object with map_step / adam_step /
+    grad_slab of the same meaning); every rank ends each step with bit-identical parameters because every rank applies
+    the same Adam update to the same all-reduced gradients."""
+
+    def __init__(self, backend, group=None):
+        self.backend, self.group = backend, group
+        self._slab = None
+
+    def step(self, stage, rays_o, rays_d, gt_depth, gt_color, lr, w_color=0.2, use_color=True, flags=3, loss=None,
+             gt_depth_max=None):
+        if gt_depth_max is None:
+            gt_depth_max = global_depth_max(gt_depth, self.group)
+        self.backend.map_step(stage, rays_o, rays_d, gt_depth, gt_color, gt_depth_max, w_color, use_color, flags=flags, loss=loss)
+        if self._slab is None:
+            self._slab = self.backend.grad_slab()
+        allreduce_grads(self._slab, self.group)
+        self.backend.adam_step(lr)
+        return gt_depth_max

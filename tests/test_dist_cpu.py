@@ -1,0 +1,110 @@
+"""CPU test (-m "not gpu") of the N > 1 path: world size 2 over gloo.  The sharding / all-reduce host logic
+(nice-slam-cpp_amd/dist.py, the code bench.py runs per rank) is driven with the CPU oracle standing in for the HIP
+context: two ranks on ray shards + one all-reduce per step must reproduce the single-process full-batch step."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """same interface as nice_slam_cpp_amd.Context for the calls ShardedMapper makes (test stand-in)"""
+
+    def __init__(self, sc):
+        from oracle.nso import Oracle
+        self.o = Oracle("f64")
+        self.bound = sc["bound"]
+        self.grids = {k: v.astype(np.float64) for k, v in sc["grids"].items()}
+        self.decs = {k: v.astype(np.float64) for k, v in sc["decoders"].items()}
+        self.levels = ("middle", "fine", "color")
+        sizes = [self.grids[k].size for k in self.levels] + [self.decs["color"].size, 1]
+        self.off = np.concatenate([[0], np.cumsum(sizes)])
+        self.slab = torch.zeros(int(self.off[-1]), dtype=torch.float64)
+        self.mom = {k: (np.zeros_like(self.grids[k]), np.zeros_like(self.grids[k])) for k in self.levels}
+        self.dm, self.dv = np.zeros_like(self.decs["color"]), np.zeros_like(self.decs["color"])
+        self.t = 0
+
+    def grad_slab(self):
+        return self.slab
+
+    def map_step(self, stage, ro, rd, gd, gc, gmax, w_color, use_color, flags=3, loss=None):
+        o, op = self.o, self.o.opts(self.bound)
+        fw = o.render_forward(op, self.grids, self.decs, stage, ro, rd, gd, gt_depth_max=gmax)
+        l, g_d, g_c = o.loss_map(fw["depth"], fw["rgb"], gd, gc, w_color, use_color)
+        bw = o.render_backward(op, self.grids, self.decs, stage, ro, rd, gd, gmax, g_c, g_d, None, want_rays=False)
+        s = self.slab.numpy()
+        for i, k in enumerate(self.levels):
+            s[self.off[i]:self.off[i + 1]] += bw["g_grids"][k].ravel()
+        s[self.off[3]:self.off[4]] += bw["g_decoders"]["color"]
+        s[self.off[4]] += l
+
+    def adam_step(self, lr):
+        self.t += 1
+        s = self.slab.numpy()
+        for i, k in enumerate(self.levels):
+            g = s[self.off[i]:self.off[i + 1]].reshape(self.grids[k].shape)
+            self.o.adam_step(self.grids[k], g, self.mom[k][0], self.mom[k][1], lr[2 + i], self.t)
+        self.o.adam_step(self.decs["color"], s[self.off[3]:self.off[4]].copy(), self.dm, self.dv, lr[0], self.t)
+        self.loss = float(s[self.off[4]])
+        s[:] = 0
+
+
+def _scene_and_rays():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    sc = scenes.make_scene(5, scenes.SMALL_GRID_SHAPES, grid_std=0.1)
+    rays = scenes.make_rays(6, 37, sc["bound"], n_frames=1)          # odd count: uneven shards
+    return sc, rays
+
+
+LR = [0.005, 0.0, 0.005, 0.005, 0.005, 0.0]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nice_slam_cpp_amd.dist as nd
+    sc, rays = _scene_and_rays()
+    lo, hi = nd.shard_range(rays["rays_o"].shape[0], rank, world)
+    be = OracleBackend(sc)
+    mapper = nd.ShardedMapper(be)
+    sl = slice(lo, hi)
+    gmaxes = []
+    for _ in range(2):
+        g = mapper.step("color", rays["rays_o"][sl], rays["rays_d"][sl], torch.tensor(rays["gt_depth"][sl]).numpy() if False else rays["gt_depth"][sl],
+                        rays["gt_color"][sl], LR, gt_depth_max=nd.global_depth_max(torch.tensor(rays["gt_depth"][sl])))
+        gmaxes.append(g)
+    np.savez(out_path % rank, fine=be.grids["fine"], color=be.grids["color"], dec=be.decs["color"], loss=be.loss, gmax=gmaxes[0], lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_mapping_equals_single_process(tmp_path):
+    sys.path.insert(0, ROOT)
+    import nice_slam_cpp_amd.dist as nd
+    assert [nd.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    out = str(tmp_path / "rank%d.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    sc, rays = _scene_and_rays()
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 19, 19, 37)
+    assert float(r0["gmax"]) == float(r1["gmax"]) == float(rays["gt_depth"].max())       # batch-global statistic
+    # replicas stay bit-identical without any broadcast
+    for k in ("fine", "color", "dec"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert float(r0["loss"]) == float(r1["loss"])
+    # and equal the single-process full-batch result (fp64 oracle: only the summation order differs)
+    be = OracleBackend(sc)
+    m = nd.ShardedMapper(be)
+    for _ in range(2):
+        m.step("color", rays["rays_o"], rays["rays_d"], rays["gt_depth"], rays["gt_color"], LR, gt_depth_max=float(rays["gt_depth"].max()))
+    for k, ref in (("fine", be.grids["fine"]), ("color", be.grids["color"]), ("dec", be.decs["color"])):
+        assert np.abs(r0[k] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
+    assert abs(float(r0["loss"]) - be.loss) < 1e-9 * abs(be.loss)

@@ -258,3 +258,73 @@ def test_mapping_steps_match_oracle(oracle32):
         assert np.array_equal(got[:, ~masks[k]], sc["grids"][k][:, ~masks[k]])      # unmasked voxels never move
     assert rel_l2(ctx.decoder_download("color"), decs["color"]) < TOL
     assert np.array_equal(ctx.decoder_download("fine"), sc["decoders"]["fine"])
+
+
+def test_tracking_steps_match_oracle(oracle32, oracle64):
+    """Tracker::optimize_cam_in_batch (src/Tracker.cpp:41-89): pose 7-vector after Adam iterations, 1e-4 relative L2.
+    Pixel indices are an input (torch::randint cannot be matched)."""
+    sc = _scene(31, grid_std=0.3)
+    b = sc["bound"]
+    rays0 = scenes.make_rays(32, 200, b, H=480, W=640, fx=360.0, fy=360.0, cx=320.0, cy=240.0, n_frames=1, edge=20)
+    intr = rays0["intr"]
+    c2w0 = rays0["c2w"][0]
+    # start from a slightly perturbed pose (quaternion of a small rotation composed with the true one is overkill here:
+    # the test needs identical inputs on both sides, not a converging tracker)
+    R = c2w0[:3, :3].astype(np.float64)
+    qw = np.sqrt(max(1e-12, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    q = np.array([qw, (R[2, 1] - R[1, 2]) / (4 * qw), (R[0, 2] - R[2, 0]) / (4 * qw), (R[1, 0] - R[0, 1]) / (4 * qw)])
+    cam0 = np.concatenate([q * 1.3, c2w0[:3, 3] + np.array([0.02, -0.01, 0.015])]).astype(np.float32)   # un-normalised q is allowed
+    pi, pj = rays0["pix_i"], rays0["pix_j"]
+    gt_d, gt_c = rays0["gt_depth"], rays0["gt_color"]
+    ctx = make_ctx(sc)
+    cam = cu(cam0); m = torch.zeros(7, device="cuda"); v = torch.zeros(7, device="cuda")
+    pi_t, pj_t = cu(pi, torch.int32), cu(pj, torch.int32)
+    loss_t = torch.zeros(1, device="cuda")
+    losses, g_first = [], None
+    for step in range(1, 4):
+        c2w = ctx.camera_from_tensor(cam)
+        ro, rd = ctx.rays_from_pixels(pi_t, pj_t, intr, c2w)
+        keep = ctx.inside_filter(ro, rd, cu(gt_d))
+        idx = torch.nonzero(keep).squeeze(1)
+        ro_k, rd_k = ro[idx].contiguous(), rd[idx].contiguous()
+        gd_k, gc_k = cu(gt_d)[idx].contiguous(), cu(gt_c)[idx].contiguous()
+        g_ro = torch.empty_like(ro_k); g_rd = torch.empty_like(rd_k)
+        ctx.track_step("color", ro_k, rd_k, gd_k, gc_k, -1.0, 0.5, True, True, True, flags=4, loss=loss_t, g_rays=(g_ro, g_rd))
+        g_c2w = ctx.rays_backward(pi_t[idx].contiguous(), pj_t[idx].contiguous(), intr, g_ro, g_rd)
+        g_cam = ctx.camera_backward(cam, g_c2w)
+        ctx.adam_vector(cam, g_cam, m, v, 1e-2, step)
+        losses.append(float(loss_t))
+        if step == 1:
+            g_first = g_cam.cpu().numpy()
+
+    def oracle_track(o):
+        cam_ref = cam0.astype(o.dt); m_ref = np.zeros(7, o.dt); v_ref = np.zeros(7, o.dt)
+        ls, g1 = [], None
+        for step in range(1, 4):
+            c2w_r = o.camera_from_tensor(cam_ref)
+            ro_r, rd_r = o.rays_from_pixels(pi, pj, *intr, c2w_r)
+            keep_r = o.inside_filter(b, ro_r, rd_r, gt_d)
+            op = o.opts(b)
+            fw = o.render_forward(op, sc["grids"], sc["decoders"], "color", ro_r[keep_r], rd_r[keep_r], gt_d[keep_r])
+            l_ref, gD, gC, gV = o.loss_track(fw["depth"], fw["rgb"], fw["var"], gt_d[keep_r], gt_c[keep_r], 0.5, True, True, True)
+            bw = o.render_backward(op, sc["grids"], sc["decoders"], "color", ro_r[keep_r], rd_r[keep_r], gt_d[keep_r], -1.0, gC, gD, None,
+                                   want_grids=False, want_decoders=False)
+            g_c2w_r = o.rays_backward(pi[keep_r], pj[keep_r], *intr, bw["g_rays_o"], bw["g_rays_d"])
+            g_cam_r = o.camera_backward(cam_ref, g_c2w_r)
+            if step == 1:
+                g1 = g_cam_r.copy()
+            o.adam_step(cam_ref, g_cam_r, m_ref, v_ref, 1e-2, step)
+            ls.append(l_ref)
+        return cam_ref, ls, g1
+
+    cam32, l32, g32 = oracle_track(oracle32)
+    cam64, l64, g64 = oracle_track(oracle64)
+    for a, r in zip(losses, l32):
+        assert abs(a - r) < 1e-3 * abs(r), (a, r)
+    # the pose gradient sums ReLU-kinked per-sample terms over ~10^4 samples: two fp32 evaluations differ by whatever
+    # the fp32 oracle differs from the fp64 one; the HIP path must be at least that close to the fp64 truth
+    e_g, e_g_ref = rel_l2(g_first, g64), rel_l2(g32, g64)
+    assert e_g < max(5 * TOL, 3 * e_g_ref), (e_g, e_g_ref)
+    e_p, e_p_ref = rel_l2(cam.cpu().numpy(), cam64), rel_l2(cam32, cam64)
+    assert e_p < max(TOL, 3 * e_p_ref), (e_p, e_p_ref)
+    print("tracking: grad err hip %.2e oracle32 %.2e | pose err hip %.2e oracle32 %.2e" % (e_g, e_g_ref, e_p, e_p_ref))

@@ -1,0 +1,74 @@
+"""Pins row A6 (GaussianFFT embedding) of the oracle against oracle/_ref: the reference's own
+src/models/GaussianFFT.cpp compiled from /root/reference by `make -C oracle ref` (the only reference translation
+unit that builds in this image).  The .so travels to the GPU box; the reference sources do not."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libref_gaussianfft.so")
+
+
+def _ref_embed(x, B):
+    import torch  # noqa: F401  (libtorch must be loaded before the reference object)
+    lib = C.CDLL(LIB)
+    x = np.ascontiguousarray(x, np.float32); B = np.ascontiguousarray(B, np.float32)
+    out = np.zeros((x.shape[0], 93), np.float32)
+    rc = lib.ref_gaussianfft_forward(x.ctypes.data_as(C.c_void_p), x.shape[0], B.ctypes.data_as(C.c_void_p), 93,
+                                     out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_oracle_embedding_matches_reference_gaussianfft(oracle32):
+    """raw output of the middle decoder depends on sin(pB) only through the embedding: isolate it by comparing the
+    oracle's embedding (recovered through a decoder whose first layer is the identity on 32 embedding rows)"""
+    rng = np.random.default_rng(0)
+    sc = scenes.make_scene(2, scenes.SMALL_GRID_SHAPES)
+    P = sc["decoders"]["middle"].copy()
+    B = P[:3 * 93].reshape(3, 93)
+    pts = rng.uniform(-3, 3, (257, 3)).astype(np.float32)
+    ref = _ref_embed(pts, B)
+    # independent numpy statement of the same op in fp64
+    truth = np.sin(pts.astype(np.float64) @ B.astype(np.float64))
+    assert np.abs(ref - truth).max() < 5e-5          # fp32 argument rounding at |x| ~ 1e2
+    # oracle path: zero everything except pts_linear[0] = selector of embedding row k -> h0[k] = relu(e_k) ...
+    # simpler and exact: use the oracle's decoder on a network that copies e through: compare via eval of
+    # sin(pB) from nso's own forward (aux raw is not enough), so call the C embedding through a 1-layer probe:
+    from oracle import torch_ref as T
+    import torch
+    e_t = torch.sin(torch.matmul(torch.tensor(pts), torch.tensor(B))).numpy()
+    assert np.abs(ref - e_t).max() == 0.0             # same ATen ops -> bit-identical to the reference object code
+    # the C oracle evaluates p0*B0 + p1*B1 + p2*B2 then sinf: within 1 ulp of the argument of the reference
+    lay0 = 3 * 93
+    P2 = np.zeros_like(P)
+    P2[:lay0] = P[:lay0]
+    # probe decoder: W0 = I on rows 0..31 (cols 0..31), all later blocks identity-free; read a[0] via ReLU(e)+...:
+    # route e[0:32] to the output one at a time
+    for k in (0, 17, 31, 64, 92):
+        Pk = np.zeros_like(P)
+        Pk[:lay0] = P[:lay0]
+        o = lay0
+        W0 = np.zeros((32, 93), np.float32); W0[0, k] = 1.0                       # a0[0] = e_k
+        Pk[o:o + 32 * 93] = W0.ravel(); o += 32 * 93 + 32
+        for i in (1, 2):
+            W = np.zeros((32, 32), np.float32); W[0, 0] = 1.0
+            Pk[o:o + 1024] = W.ravel(); o += 1024 + 32
+        W3 = np.zeros((32, 125), np.float32); W3[0, 93] = 1.0
+        Pk[o:o + 32 * 125] = W3.ravel(); o += 32 * 125 + 32
+        W4 = np.zeros((32, 32), np.float32); W4[0, 0] = 1.0
+        Pk[o:o + 1024] = W4.ravel(); o += 1024 + 32
+        o += 5 * (32 * 32 + 32)                                                    # fc = 0
+        Pk[o] = 1.0                                                                # output = h4[0] = relu(e_k)
+        decs = dict(sc["decoders"]); decs["middle"] = Pk
+        ro = pts; rd = np.tile(np.array([[0.0, 0.0, 1e-9]], np.float32), (pts.shape[0], 1))
+        op = oracle32.opts(np.array([[-50, 50], [-50, 50], [-50, 50]], np.float32), n_samples=1, n_surface=0)
+        fw = oracle32.render_forward(op, sc["grids"], decs, "middle", ro, rd, None, want_aux=True)
+        got = fw["raw"][:, 0, 3]
+        # z = 0.01 -> p = o + d*0.01 = o (d ~ 0): relu(e_k)
+        assert np.abs(got - np.maximum(ref[:, k], 0)).max() < 2e-5

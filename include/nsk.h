@@ -108,6 +108,11 @@ int nsk_render_forward(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, co
  * outside the bound. */
 int nsk_eval_points(nsk_ctx* ctx, int stage, int M, const float* d_points, float* d_raw);
 
+/* raw2outputs_nerf_color (include/torchlib/utils.h:148-172) on its own: d_raw [N][S][4] (rgb, sigma), d_z [N][S] sorted,
+ * d_rays_d [N][3]; occupancy 0 = density branch (what src/Renderer.cpp:125 passes). */
+int nsk_raw2outputs(nsk_ctx* ctx, int N, int S, const float* d_raw, const float* d_z, const float* d_rays_d, int occupancy,
+                    float* d_rgb, float* d_depth, float* d_var, float* d_weights);
+
 /* Backward of render_batch_ray given upstream gradients (what loss.backward() at src/Mapper.cpp:444 /
  * src/Tracker.cpp:84 is meant to do).  The forward is recomputed internally.
  *   d_g_rgb [N][3], d_g_depth [N], d_g_var [N] or NULL (depth_var detached).

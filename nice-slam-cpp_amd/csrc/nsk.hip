@@ -261,6 +261,36 @@ __global__ void k_eval_finish(int M, int stage, const float* pts, const float* b
     *reinterpret_cast<f4*>(raw + (size_t)m * 4) = (f4){c[0], c[1], c[2], inb ? occ : 100.f};
 }
 
+// raw2outputs_nerf_color as a stand-alone op (reference include/torchlib/utils.h:148-172): one wave per ray
+__global__ __launch_bounds__(256) void k_raw2outputs(int N, int S, int occupancy, const float* __restrict__ raw, const float* __restrict__ zv,
+                                                     const float* __restrict__ rays_d, float* rgb, float* depth, float* var, float* weights)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const bool act = lane < S;
+    const size_t m = (size_t)n * S + (act ? lane : S - 1);
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    const float z = zv[m];
+    const f4 r4 = *reinterpret_cast<const f4*>(raw + m * 4);
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float znext = __shfl_down(z, 1);
+    const float dist = ((lane + 1 < S) ? (znext - z) : 1e10f) * nrm;
+    float alpha = occupancy ? 1.f / (1.f + expf(-10.f * r4[3])) : 1.f - expf(-fmaxf(r4[3], 0.f) * dist);
+    if (!act) alpha = 0.f;
+    float incl = act ? (1.f - alpha + 1e-10f) : 1.f;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float up = __shfl_up(incl, o); if (lane >= o) incl *= up; }
+    float T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.f;
+    const float w = act ? alpha * T : 0.f;
+    const float D = wave_sum(w * z);
+    const float cr = wave_sum(w * r4[0]), cg = wave_sum(w * r4[1]), cb = wave_sum(w * r4[2]);
+    const float V = wave_sum(w * (z - D) * (z - D));
+    if (weights && act) weights[m] = w;
+    if (lane == 0) { depth[n] = D; var[n] = V; rgb[3 * n] = cr; rgb[3 * n + 1] = cg; rgb[3 * n + 2] = cb; }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------
@@ -866,6 +896,17 @@ extern "C" int nsk_render_forward(nsk_ctx* c, int stage, int N, const float* ro,
     { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());
     account(c, stage, N * S, N, false, 0);
+    return 0;
+}
+
+extern "C" int nsk_raw2outputs(nsk_ctx* c, int N, int S, const float* raw, const float* z, const float* rd, int occupancy,
+                               float* rgb, float* depth, float* var, float* weights)
+{
+    if (!c || !raw || !z || !rd || !rgb || !depth || !var) return fail("nsk_raw2outputs: null argument");
+    if (N < 1 || S < 1 || S > 64) return fail("nsk_raw2outputs: need N >= 1 and 1 <= S <= 64");
+    HIPCHK(hipSetDevice(c->device));
+    k_raw2outputs<<<(N + 3) / 4, 256, 0, c->stream>>>(N, S, occupancy, raw, z, rd, rgb, depth, var, weights);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -19,7 +19,7 @@ SYMBOLS = (
     "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
     "nsk_set_render_opts", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask",
     "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
-    "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_render_backward", "nsk_map_step",
+    "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
     "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
     "nsk_adam_reset", "nsk_zero_grads", "nsk_grad_slab", "nsk_allreduce_grads", "nsk_last_call_stats",
@@ -218,6 +218,17 @@ class Context:
         raw = torch.empty(M, 4, device=pts.device)
         _chk(lib().nsk_eval_points(self.h, _stage(stage), M, _ptr(pts), _ptr(raw)))
         return raw
+
+    @_ordered
+    def raw2outputs(self, raw, z, rays_d, occupancy=False):
+        import torch
+        N, S = z.shape
+        dev = z.device
+        rgb = torch.empty(N, 3, device=dev); depth = torch.empty(N, device=dev); var = torch.empty(N, device=dev)
+        w = torch.empty(N, S, device=dev)
+        _chk(lib().nsk_raw2outputs(self.h, N, S, _ptr(raw), _ptr(z), _ptr(rays_d), int(occupancy), _ptr(rgb), _ptr(depth),
+                                   _ptr(var), _ptr(w)))
+        return rgb, depth, var, w
 
     @_ordered
     def render_backward(self, stage, rays_o, rays_d, gt_depth, gt_depth_max, g_rgb, g_depth, g_var=None, flags=GRAD_GRIDS):

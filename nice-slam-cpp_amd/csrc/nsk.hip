@@ -952,7 +952,10 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
         A.flags = flags;
         MA.which[n] = w; MA.train[n] = train ? 1 : 0;
-        cost[n] = train ? 1000 : 120;      // frozen roles are bound by the chip-wide atomic rate, not by their CU count
+        // measured (1000 and 10000 rays, colour stage): ~65 us per 8-task iteration of the trainable role against ~10 us per
+        // task of a frozen role; 170 minimised decode_bwd_multi at both sizes (130: 159/1365 us, 170: 140/1155, 200: 193/1213)
+        static const int frozen_cost = getenv("NSK_FROZEN_COST") ? atoi(getenv("NSK_FROZEN_COST")) : 170;
+        cost[n] = train ? 1000 : frozen_cost;
         lds = std::max(lds, bwd_lds_bytes(w, train));
         if (train) train_role = train_role == -1 ? n : -2;     // -2: more than one trainable decoder -> separate launches below
         if (train) c->touched[NSK_GROUP_DECODERS] = true;

@@ -276,28 +276,52 @@ struct Act {               // activations of one 16-sample tile, D layout
     unsigned long long mask;   // ReLU bits, layer l -> bits 8l..8l+7
 };
 
-// sin / cos with a 3-term Cody-Waite reduction by pi/2 using FMA (each product is exact inside the FMA) and
-// minimax polynomials on [-pi/4, pi/4]: ~1 ulp for |x| < 1e5 (arguments here are |p| * 25 * N(0,1) ~ 1e2).
-// The library sinf carries a Payne-Hanek path that costs ~100 VALU instructions per call.
+// sin / cos with a 3-term Cody-Waite reduction by pi using FMA (each product is exact inside the FMA) and ONE
+// near-minimax polynomial each on [-pi/2, pi/2]: max abs error 1.4e-7 for |x| < 1e4 (arguments here are
+// |p| * 25 * N(0,1) ~ 1e2).  The library sinf carries a Payne-Hanek path (~100 VALU instructions per call); VALU
+// instructions share the SIMD's fp32 pipe with the fp32 MFMAs, so every one of them adds to the kernel time.
+__device__ __forceinline__ float nsk_reduce_pi(float x, int& k_out)
+{
+    const float k = rintf(x * 0.318309886f);                 // 1/pi
+    float r = fmaf(k, -3.14159250259399414062f, x);          // pi split: 0x1.921fb4p+1
+    r = fmaf(k, -1.50995788317231927067e-07f, r);            //           0x1.4442d0p-23
+    r = fmaf(k, -1.07806050599155295e-14f, r);               //           0x1.846988p-47
+    k_out = (int)k;
+    return r;
+}
+__device__ __forceinline__ float nsk_sin_poly(float r, float u)
+{
+    float p = fmaf(-2.3866771670100206e-08f, u, 2.752401314864983e-06f);
+    p = fmaf(p, u, -0.00019840836466755718f);
+    p = fmaf(p, u, 0.008333330973982811f);
+    p = fmaf(p, u, -0.1666666716337204f);
+    p = fmaf(p, u, 1.0f);
+    return r * p;
+}
+__device__ __forceinline__ float nsk_cos_poly(float u)
+{
+    float q = fmaf(1.9888739544171585e-09f, u, -2.752338446043723e-07f);
+    q = fmaf(q, u, 2.4801007384667173e-05f);
+    q = fmaf(q, u, -0.0013888883404433727f);
+    q = fmaf(q, u, 0.0416666679084301f);
+    q = fmaf(q, u, -0.5f);
+    return fmaf(q, u, 1.0f);
+}
+__device__ __forceinline__ float nsk_sin(float x)
+{
+    int k;
+    const float r = nsk_reduce_pi(x, k);
+    const float s = nsk_sin_poly(r, r * r);
+    return __int_as_float(__float_as_int(s) ^ (k << 31));    // (-1)^k
+}
 __device__ __forceinline__ void nsk_sincos(float x, float& sn, float& cs)
 {
-    const float k = rintf(x * 0.636619747f);                 // 2/pi
-    float r = fmaf(k, -1.57079625129699707031f, x);          // pi/2 split: 0x1.921fb4p+0
-    r = fmaf(k, -7.54978941586159635335e-08f, r);            //             0x1.4442d0p-24
-    r = fmaf(k, -5.39030252995776476e-15f, r);               //             0x1.846988p-48
-    const float r2 = r * r;
-    float ps = fmaf(r2, 2.60831598e-6f, -1.98106880e-4f);    // sin(r) = r + r^3 * P(r^2)
-    ps = fmaf(ps, r2, 8.33307430e-3f);
-    ps = fmaf(ps, r2, -1.66666597e-1f);
-    const float s = fmaf(ps * r2, r, r);
-    float pc = fmaf(r2, 2.44331571e-5f, -1.38873163e-3f);    // cos(r) = 1 - r^2/2 + r^4 * Q(r^2)
-    pc = fmaf(pc, r2, 4.16666457e-2f);
-    const float c = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
-    const int q = (int)k;
-    const float s1 = (q & 1) ? c : s;
-    const float c1 = (q & 1) ? s : c;
-    sn = (q & 2) ? -s1 : s1;
-    cs = ((q + 1) & 2) ? -c1 : c1;
+    int k;
+    const float r = nsk_reduce_pi(x, k);
+    const float u = r * r;
+    const int sg = k << 31;
+    sn = __int_as_float(__float_as_int(nsk_sin_poly(r, u)) ^ sg);
+    cs = __int_as_float(__float_as_int(nsk_cos_poly(u)) ^ sg);
 }
 
 // embedding e = sin(p B) (reference src/models/GaussianFFT.cpp:10-15), optional cos for the backward
@@ -314,8 +338,8 @@ __device__ __forceinline__ void embed(const float* __restrict__ Bm /*[3][96]*/, 
         for (int i = 0; i < 4; ++i) {
             int k = 16 * q + 4 * g + i;
             float s = add_rn(add_rn(mul_rn(px, b0[i]), mul_rn(py, b1[i])), mul_rn(pz, b2[i]));
-            float sv, cv;
-            nsk_sincos(s, sv, cv);
+            float sv, cv = 0.f;
+            if (WANT_COS) nsk_sincos(s, sv, cv); else sv = nsk_sin(s);
             xe[q][i] = k < NSK_E ? sv : 0.f;
             xcos[q][i] = (WANT_COS && k < NSK_E) ? cv : 0.f;
         }
@@ -440,7 +464,7 @@ __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int n
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const float* imgf = reinterpret_cast<const float*>(smem);
     const int ntasks = (A.M + 15) >> 4;
-    for (int task = bid * 8 + wave; task < ntasks; task += nb * 8) {
+    for (int task = bid * NW + wave; task < ntasks; task += nb * NW) {
         asm volatile("" ::: "memory");      // keep the LDS fragment reads inside the loop (LICM would hoist + spill them)
         const int m = task * 16 + j;
         const int mm = min(m, A.M - 1);

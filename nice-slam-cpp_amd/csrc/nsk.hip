@@ -55,7 +55,8 @@ __global__ void k_adam(int n, float* __restrict__ p, float* __restrict__ g, floa
     *g4 = (f4)(0.f);
 }
 
-struct AdamSeg { float* p; float* g; float* m; float* v; const uint8_t* mask; int n; float step_size, bc2s; int blk_end; };
+struct AdamSeg { float* p; float* g; float* m; float* v; const uint8_t* mask; int n; float step_size, bc2s; int blk_end;
+                 const int* inv_f; const int* inv_b; float* fimg; float* bimg; };   // decoders: image position of each parameter (-1 none)
 struct AdamArgs { AdamSeg s[8]; int n; float b1, b2, eps; };
 // all parameter groups of one optimiser step in one launch (3 grid levels + trainable decoders)
 __global__ void k_adam_multi(AdamArgs A)
@@ -78,6 +79,14 @@ __global__ void k_adam_multi(AdamArgs A)
     }
     reinterpret_cast<f4*>(S.p)[i] = pp; reinterpret_cast<f4*>(S.m)[i] = mm; reinterpret_cast<f4*>(S.v)[i] = vv;
     *g4 = (f4)(0.f);
+    if (S.inv_f) {      // keep the MFMA fragment images of a trainable decoder in step with its parameters
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int fi = S.inv_f[4 * i + k], bi = S.inv_b[4 * i + k];
+            if (fi >= 0) S.fimg[fi] = pp[k];
+            if (bi >= 0) S.bimg[bi] = pp[k];
+        }
+    }
 }
 
 struct PackSeg { float* img; const int* idx; const float* P; int n; int blk_end; };
@@ -306,6 +315,7 @@ struct DecState {
     float* p = nullptr; float* m = nullptr; float* s = nullptr;
     float* fimg = nullptr; float* bimg = nullptr;
     int* fidx = nullptr; int* bidx = nullptr;
+    int* finv = nullptr; int* binv = nullptr;     // inverse of fidx / bidx: image position of each canonical parameter
     int fimg_n = 0, bimg_n = 0;
     int trainable = 0;
     bool loaded = false;
@@ -431,7 +441,7 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
     for (int i = 0; i < 4; ++i) {
         hipFree(c->grid[i].v); hipFree(c->grid[i].m); hipFree(c->grid[i].s); hipFree(c->grid[i].mask);
         hipFree(c->dec[i].p); hipFree(c->dec[i].m); hipFree(c->dec[i].s); hipFree(c->dec[i].fimg); hipFree(c->dec[i].bimg);
-        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx);
+        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv);
     }
     hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal);
     free_ws(c->ws);
@@ -634,6 +644,14 @@ extern "C" int nsk_decoder_upload(nsk_ctx* c, int w, const float* h, size_t n)
         HIPCHK(hipMalloc(&D.fidx, fi.size() * 4)); HIPCHK(hipMalloc(&D.bidx, bi.size() * 4));
         HIPCHK(hipMemcpy(D.fidx, fi.data(), fi.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(D.bidx, bi.data(), bi.size() * 4, hipMemcpyHostToDevice));
+        {
+            std::vector<int> finv(n4, -1), binv(n4, -1);
+            for (size_t k = 0; k < fi.size(); ++k) if (fi[k] >= 0) { if (finv[fi[k]] != -1) return fail("decoder %d: parameter %d appears twice in the forward image", w, fi[k]); finv[fi[k]] = (int)k; }
+            for (size_t k = 0; k < bi.size(); ++k) if (bi[k] >= 0) { if (binv[bi[k]] != -1) return fail("decoder %d: parameter %d appears twice in the backward image", w, bi[k]); binv[bi[k]] = (int)k; }
+            HIPCHK(hipMalloc(&D.finv, n4 * 4)); HIPCHK(hipMalloc(&D.binv, n4 * 4));
+            HIPCHK(hipMemcpy(D.finv, finv.data(), n4 * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(D.binv, binv.data(), n4 * 4, hipMemcpyHostToDevice));
+        }
         CHK(rebuild_slab(c));
     }
     HIPCHK(hipMemcpyAsync(D.p, h, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -930,7 +948,8 @@ extern "C" int nsk_eval_points(nsk_ctx* c, int stage, int M, const float* pts, f
 }
 
 // decoders' backward after k_composite wrote g_raw: ONE launch for every decoder of the stage that needs it
-static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, unsigned flags, float* g_ro, float* g_rd)
+static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, unsigned flags, float* g_ro, float* g_rd,
+                         float* d_loss = nullptr)
 {
     const bool rays = (flags & NSK_GRAD_RAYS) != 0;
     const bool grids = (flags & NSK_GRAD_GRIDS) != 0;
@@ -962,6 +981,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         if (grids) c->touched[NSK_GROUP_COARSE + w] = true;
         ++n;
     }
+    if ((n == 0 || train_role == -2) && d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
     if (n == 0) return 0;
     if (train_role == -2) {      // rare configuration (several trainable decoders share one slab buffer): one launch each
         for (int r = 0; r < n; ++r)
@@ -970,10 +990,12 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
     }
     MA.n = n;
     split_wgs(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end);
+    const int extra = d_loss ? 1 : 0;          // one more workgroup sums the per-ray losses written by k_composite
+    if (d_loss) { MA.sum_src = c->ws.ray_loss; MA.sum_dst = d_loss; MA.sum_n = N; }
     {
         ProfScope ps(c, "decode_bwd_multi");
-        if (rays) k_decode_bwd_multi<true><<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
-        else k_decode_bwd_multi<false><<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
+        if (rays) k_decode_bwd_multi<true><<<MA.wg_end[n - 1] + extra, 512, lds, c->stream>>>(MA);
+        else k_decode_bwd_multi<false><<<MA.wg_end[n - 1] + extra, 512, lds, c->stream>>>(MA);
     }
     HIPCHK(hipGetLastError());
     if (train_role >= 0) {
@@ -1023,8 +1045,7 @@ extern "C" int nsk_map_step(nsk_ctx* c, int stage, int N, const float* ro, const
     if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
     { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());
-    if (d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
-    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
+    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd, d_loss));
     account(c, stage, N * S, N, true, flags);
     return 0;
 }
@@ -1061,8 +1082,7 @@ extern "C" int nsk_track_step(nsk_ctx* c, int stage, int N, const float* ro, con
     if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
     { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());
-    if (d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
-    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
+    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd, d_loss));
     account(c, stage, N * S, N, true, flags);
     return 0;
 }
@@ -1186,11 +1206,8 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
             AdamSeg& S = AA.s[AA.n++];
             adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, S.step_size, S.bc2s);
             S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.mask = nullptr; S.n = n4;
+            S.inv_f = D.finv; S.inv_b = D.binv; S.fimg = D.fimg; S.bimg = D.bimg;
             blocks += (n4 / 4 + 255) / 256; S.blk_end = blocks;
-            PackSeg& P1 = PA.s[PA.n++];
-            P1.img = D.fimg; P1.idx = D.fidx; P1.P = D.p; P1.n = D.fimg_n; pblocks += (D.fimg_n + 255) / 256; P1.blk_end = pblocks;
-            PackSeg& P2 = PA.s[PA.n++];
-            P2.img = D.bimg; P2.idx = D.bidx; P2.P = D.p; P2.n = D.bimg_n; pblocks += (D.bimg_n + 255) / 256; P2.blk_end = pblocks;
         }
         c->touched[NSK_GROUP_DECODERS] = false;
     }

@@ -513,7 +513,22 @@ template <int WHICH>
 __global__ __launch_bounds__(512) void k_decode_fwd(DecArgs A) { decode_fwd_body<WHICH>(A, blockIdx.x, gridDim.x); }
 
 // one launch for all decoders of a stage: workgroups [wg_end[r-1], wg_end[r]) serve decoder which[r]
-struct MultiArgs { DecArgs a[3]; int which[3]; int train[3]; int wg_end[3]; int n; };
+struct MultiArgs {
+    DecArgs a[3]; int which[3]; int train[3]; int wg_end[3]; int n;
+    const float* sum_src; float* sum_dst; int sum_n;      // optional: one extra workgroup sums the per-ray losses (saves a launch)
+};
+
+__device__ __forceinline__ void block_sum(const float* __restrict__ x, int n, float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) f4 smem[];      // dynamic LDS only: a static array would push the kernel past 160 KiB
+    float* sh = reinterpret_cast<float*>(smem);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += sh[w]; *out = s; }
+}
 // (a 1024-thread form, 4 waves per SIMD at 128 VGPRs, measured 126 us against 73 us for this one at 1000 rays)
 __global__ __launch_bounds__(512) void k_decode_fwd_multi(MultiArgs MA)
 {

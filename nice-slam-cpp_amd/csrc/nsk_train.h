@@ -392,6 +392,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_train(DecArgs A) { decode_bw
 template <bool RAYS>
 __global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
 {
+    if (MA.sum_n > 0 && blockIdx.x == gridDim.x - 1) { block_sum(MA.sum_src, MA.sum_n, MA.sum_dst); return; }
     int r = 0;
     while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
     const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];

@@ -168,8 +168,18 @@ def main():
     dom = max((k for k in prof if k.startswith("decode")), key=lambda k: prof[k][1])
     dom_s = prof[dom][1] / prof[dom][0] * 1e-3
     flops = 2.0 * MAC[dom] * M
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    # (profiles/r01b_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the
+    # MI355X guide prescribes for gfx950).  Only valid for the default 1000-ray workload the passes were run on.
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01b_pmc_hbm.json")
+    if os.path.exists(pmc_path) and N == 1000 and args.stage == "color":
+        pmc = json.load(open(pmc_path))
+        kname = {"decode_bwd_multi": "void k_decode_bwd_multi<false>(M", "decode_fwd_multi": "k_decode_fwd_multi(MultiArgs)"}.get(dom)
+        if kname and (kname + "|FETCH_SIZE") in pmc:
+            traffic = (2.0 * pmc[kname + "|FETCH_SIZE"] + pmc[kname + "|WRITE_SIZE"]) * 1024.0
     roof = {"bound": "mfma", "kernel": dom, "achieved": flops / dom_s / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "frac": flops / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
             "avg_launch_us": dom_s * 1e6, "alg_flops_per_launch": flops,
             "alg_bytes_per_launch": BYTES[dom] * M, "hbm_frac_same_kernel": BYTES[dom] * M / dom_s / 1e9 / PEAK_HBM_GBS}
     step_bytes = 9221.0 * M + 28.0 * sum(sc["grids"][k].size for k in ("middle", "fine", "color"))

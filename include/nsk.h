@@ -61,6 +61,12 @@ int nsk_ctx_destroy(nsk_ctx* ctx);
 int nsk_sync(nsk_ctx* ctx);                         /* hipStreamSynchronize */
 void* nsk_stream(nsk_ctx* ctx);                     /* the hipStream_t in use */
 
+/* How the decoders' matrix products are evaluated (results agree to fp32 rounding):
+ *   0 = v_mfma_f32_16x16x4_f32, plain fp32 (default);
+ *   1 = fp32 operands split into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation
+ *       (forward decoders of multi-decoder stages; everything else stays in mode 0). */
+int nsk_set_matmul_mode(nsk_ctx* ctx, int mode);
+
 /* Scene bound [[x0,x1],[y0,y1],[z0,z1]]; the reference hard-codes it in five places
  * (src/main.cpp:33, src/Renderer.cpp:15, src/Mapper.cpp:29, src/Tracker.cpp:23, src/models/MLP.cpp:53-56). */
 int nsk_set_bound(nsk_ctx* ctx, const float h_bound[6]);

@@ -3,6 +3,7 @@
 #include "../../include/nsk.h"
 #include "nsk_device.h"
 #include "nsk_train.h"
+#include "nsk_bf16.h"
 
 #include <dlfcn.h>
 #include <cstdarg>
@@ -316,6 +317,7 @@ struct DecState {
     float* fimg = nullptr; float* bimg = nullptr;
     int* fidx = nullptr; int* bidx = nullptr;
     int* finv = nullptr; int* binv = nullptr;     // inverse of fidx / bidx: image position of each canonical parameter
+    float* fimg16 = nullptr; int* fidx16 = nullptr; int frag16_n = 0, fimg16_f = 0, tail_off = 0, tail16_off = 0;   // bf16 3-piece forward image
     int fimg_n = 0, bimg_n = 0;
     int trainable = 0;
     bool loaded = false;
@@ -343,6 +345,7 @@ struct nsk_ctx {
     float* scal = nullptr;       // [0] gt max, [1] median threshold, [2] loss
     int adam_step[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
+    int matmul_mode = 0;                    // 0 fp32 MFMA, 1 bf16 3-piece split (forward)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
     // optional per-kernel timing with HIP events on the context's stream (nsk_profile_begin / _end)
     bool prof = false;
@@ -420,7 +423,8 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     SETB(0) SETB(1) SETB(2) SETB(3)
 #undef SETB
     CHK(set_lds(k_median_thr, 16384 * 4));
-    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
+    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16, 160 * 1024));
+    if (const char* e = getenv("NSK_MATMUL_MODE")) c->matmul_mode = atoi(e); CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
     *out = c;
     return 0;
 }
@@ -442,6 +446,7 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
         hipFree(c->grid[i].v); hipFree(c->grid[i].m); hipFree(c->grid[i].s); hipFree(c->grid[i].mask);
         hipFree(c->dec[i].p); hipFree(c->dec[i].m); hipFree(c->dec[i].s); hipFree(c->dec[i].fimg); hipFree(c->dec[i].bimg);
         hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv);
+        hipFree(c->dec[i].fimg16); hipFree(c->dec[i].fidx16);
     }
     hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal);
     free_ws(c->ws);
@@ -452,6 +457,14 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
 
 extern "C" int nsk_sync(nsk_ctx* c) { if (!c) return fail("null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
 extern "C" void* nsk_stream(nsk_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int nsk_set_matmul_mode(nsk_ctx* c, int mode)
+{
+    if (!c) return fail("null ctx");
+    if (mode != 0 && mode != 1) return fail("nsk_set_matmul_mode: mode must be 0 (fp32 MFMA) or 1 (bf16 3-piece split)");
+    c->matmul_mode = mode;
+    return 0;
+}
 
 extern "C" int nsk_set_bound(nsk_ctx* c, const float h_bound[6])
 {
@@ -614,6 +627,34 @@ static void build_idx(int w, std::vector<int>& fidx, std::vector<int>& bidx)
     for (int a = 0; a < 3; ++a) for (int k = 0; k < NSK_E; ++k) bidx[J::P_BM + 96 * a + k] = L.oB + NSK_E * a + k;
 }
 
+static void seg16(std::vector<int>& idx, int blk0, int NB, int Wofs, int ld, int col0, int kvalid)
+{
+    for (int b = 0; b < NB; ++b) for (int rt = 0; rt < 2; ++rt) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+        int fg = 2 * (blk0 + b) + rt, o = 16 * rt + (lane & 15), k = 32 * b + nsk_bf16_kperm(lane >> 4, j);
+        idx[((size_t)fg * 64 + lane) * 8 + j] = k < kvalid ? Wofs + o * ld + col0 + k : -1;
+    }
+}
+template <int CQ>
+static void build_idx16(const DecLayout& L, std::vector<int>& idx)
+{
+    typedef MlpFwdImgB<CQ> I;
+    idx.assign((size_t)I::NBLK * 2 * 512, -1);
+    seg16(idx, I::W0E, 3, L.oW[0], NSK_E, 0, NSK_E);
+    for (int l = 0; l < 5; ++l) seg16(idx, I::F(l), I::CB, L.oFw[l], L.c_dim, 0, L.c_dim);
+    seg16(idx, I::W1, 1, L.oW[1], 32, 0, 32); seg16(idx, I::W2, 1, L.oW[2], 32, 0, 32); seg16(idx, I::W4, 1, L.oW[4], 32, 0, 32);
+    seg16(idx, I::W3E, 3, L.oW[3], 125, 0, NSK_E); seg16(idx, I::W3H, 1, L.oW[3], 125, NSK_E, 32);
+}
+
+static int repack16(nsk_ctx* c, int w)
+{
+    DecState& D = c->dec[w];
+    if (!D.fimg16) return 0;
+    k_pack_bf16<<<(D.frag16_n + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<unsigned short*>(D.fimg16), D.fidx16, D.p, D.frag16_n);
+    k_pack<<<(740 + 255) / 256, 256, 0, c->stream>>>(D.fimg16 + D.tail16_off, D.fidx + D.tail_off, D.p, 740);     // fp32 tail: biases, Wo, bo, B
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int repack(nsk_ctx* c, int w)
 {
     DecState& D = c->dec[w];
@@ -621,6 +662,7 @@ static int repack(nsk_ctx* c, int w)
     k_pack<<<(D.fimg_n + 255) / 256, 256, 0, c->stream>>>(D.fimg, D.fidx, D.p, D.fimg_n);
     k_pack<<<(D.bimg_n + 255) / 256, 256, 0, c->stream>>>(D.bimg, D.bidx, D.p, D.bimg_n);
     HIPCHK(hipGetLastError());
+    CHK(repack16(c, w));
     return 0;
 }
 
@@ -644,6 +686,15 @@ extern "C" int nsk_decoder_upload(nsk_ctx* c, int w, const float* h, size_t n)
         HIPCHK(hipMalloc(&D.fidx, fi.size() * 4)); HIPCHK(hipMalloc(&D.bidx, bi.size() * 4));
         HIPCHK(hipMemcpy(D.fidx, fi.data(), fi.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(D.bidx, bi.data(), bi.size() * 4, hipMemcpyHostToDevice));
+        if (w != 0) {
+            std::vector<int> i16;
+            if (w == 2) { build_idx16<4>(nsk_dec_layout(w), i16); D.fimg16_f = MlpFwdImgB<4>::TOTAL_F; D.tail16_off = MlpFwdImgB<4>::P_F32; D.tail_off = MlpFwdImg<4>::P_B; }
+            else { build_idx16<2>(nsk_dec_layout(w), i16); D.fimg16_f = MlpFwdImgB<2>::TOTAL_F; D.tail16_off = MlpFwdImgB<2>::P_F32; D.tail_off = MlpFwdImg<2>::P_B; }
+            D.frag16_n = (int)i16.size();
+            HIPCHK(hipMalloc(&D.fimg16, (size_t)D.fimg16_f * 4)); HIPCHK(hipMalloc(&D.fidx16, i16.size() * 4));
+            HIPCHK(hipMemset(D.fimg16, 0, (size_t)D.fimg16_f * 4));
+            HIPCHK(hipMemcpy(D.fidx16, i16.data(), i16.size() * 4, hipMemcpyHostToDevice));
+        }
         {
             std::vector<int> finv(n4, -1), binv(n4, -1);
             for (size_t k = 0; k < fi.size(); ++k) if (fi[k] >= 0) { if (finv[fi[k]] != -1) return fail("decoder %d: parameter %d appears twice in the forward image", w, fi[k]); finv[fi[k]] = (int)k; }
@@ -744,6 +795,7 @@ static void fill_args(nsk_ctx* c, DecArgs& A, int w, int M, int S, const float* 
     A.img = reinterpret_cast<const f4*>(c->dec[w].fimg);
     A.bimg = reinterpret_cast<const f4*>(c->dec[w].bimg);
     A.img_f4 = c->dec[w].fimg_n / 4;
+    A.img16 = c->dec[w].fimg16;
     A.out = w == 3 ? c->ws.rgb4 : c->ws.occ[w];
 }
 
@@ -840,6 +892,11 @@ static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const fl
     MA.n = n;
     split_wgs(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end, 8);
     ProfScope ps(c, "decode_fwd_multi");
+    if (c->matmul_mode == 1) {
+        size_t lds16 = 0;
+        for (int r = 0; r < n; ++r) lds16 = std::max(lds16, MA.which[r] == 0 ? fwd_img_floats(0) * 4 : (size_t)c->dec[MA.which[r]].fimg16_f * 4);
+        k_decode_fwd_multi_bf16<<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);
+    } else
     k_decode_fwd_multi<<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1212,6 +1269,7 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
         c->touched[NSK_GROUP_DECODERS] = false;
     }
     if (AA.n) { ProfScope ps(c, "adam_multi"); k_adam_multi<<<blocks, 256, 0, c->stream>>>(AA); }
+    if (c->matmul_mode == 1) for (int w = 1; w < 4; ++w) if (c->dec[w].trainable && c->dec[w].loaded && AA.n) { ProfScope ps(c, "pack_bf16"); CHK(repack16(c, w)); }
     if (PA.n) { ProfScope ps(c, "pack_images"); k_pack_multi<<<pblocks, 256, 0, c->stream>>>(PA); }
     HIPCHK(hipGetLastError());
     return 0;

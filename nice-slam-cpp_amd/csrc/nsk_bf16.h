@@ -1,0 +1,217 @@
+// nsk_bf16.h -- fp32-accurate decoder forward on the bf16 matrix cores ("3-piece split").
+//
+// v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate and shares the SIMD's fp32 pipe with every VALU instruction
+// (measured: chain time and VALU time add up, profiles/README.md).  v_mfma_f32_16x16x32_bf16 is 16x faster per MAC and
+// runs on the matrix pipe proper.  An fp32 value splits exactly into three bf16 pieces x = h + m + l (8 significant
+// bits each, 24 together), so  w*x = hh + hm + mh + hl + lh + mm  + O(2^-24 |w x|): six bf16 MFMAs with fp32
+// accumulation reproduce the fp32 product (numpy emulation: 6e-8 relative on K=125 dot products, fp32 itself 2e-7).
+// Cost per K=32 block: 6 x 16 = 96 matrix-pipe cycles instead of 8 x 32 = 256 fp32-pipe cycles, plus ~45 VALU
+// operations to split a block of activations.
+//
+// Layouts.  A K=32 block of an input lives in two accumulator-layout quads (q0: features 32b + 4g + i, q1:
+// 32b + 16 + 4g + i); lane group g therefore supplies the eight k values  f(g,j) = j<4 ? 4g+j : 16+4g+(j-4)  of the
+// bf16 B operand (k = 8g + j).  Weights are stored as A fragments in the same k order, three pieces per fragment:
+//     image16[((fg * 3 + piece) * 64 + lane) * 8 + j] = piece(W[16 rt + (lane&15)][col0 + 32 b + f(lane>>4, j)])
+// with fg = 2 * (segment block index) + rt.
+#pragma once
+#include "nsk_device.h"
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+template <int CQ>
+struct MlpFwdImgB {                               // block (K=32) indices of the segments; fragment group = 2*blk + rt
+    static constexpr int CB = CQ / 2;
+    static constexpr int W0E = 0;                 // 3 blocks
+    static constexpr int F0 = W0E + 3;
+    static constexpr int W1 = F0 + CB;
+    static constexpr int F1 = W1 + 1;
+    static constexpr int W2 = F1 + CB;
+    static constexpr int F2 = W2 + 1;
+    static constexpr int W3E = F2 + CB;           // 3 blocks
+    static constexpr int W3H = W3E + 3;
+    static constexpr int F3 = W3H + 1;
+    static constexpr int W4 = F3 + CB;
+    static constexpr int F4 = W4 + 1;
+    static constexpr int NBLK = F4 + CB;          // 15 (CQ=2), 20 (CQ=4)
+    static constexpr int FRAG_BYTES = NBLK * 2 * 3 * 1024;
+    static constexpr int P_F32 = FRAG_BYTES / 4;  // float offset of the plain fp32 tail (same order as MlpFwdImg)
+    static constexpr int P_B = P_F32;
+    static constexpr int P_BC = P_B + 160;
+    static constexpr int P_WO = P_BC + 160;
+    static constexpr int P_BO = P_WO + 128;
+    static constexpr int P_BM = P_BO + 4;
+    static constexpr int TOTAL_F = P_BM + 288;    // total size in floats
+    __host__ __device__ static constexpr int W(int l) { return l == 1 ? W1 : (l == 2 ? W2 : (l == 4 ? W4 : -1)); }
+    __host__ __device__ static constexpr int F(int l) { return l == 0 ? F0 : (l == 1 ? F1 : (l == 2 ? F2 : (l == 3 ? F3 : F4))); }
+};
+
+__host__ __device__ inline int nsk_bf16_kperm(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); }
+
+// split fp32 -> three bf16 pieces (round to nearest even each; the residual of one piece feeds the next)
+struct B3 { bf8 h, m, l; };
+__device__ __forceinline__ B3 split_block(f4 q0, f4 q1)
+{
+    B3 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? q0[j] : q1[j - 4];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        r.h[j] = h; r.m[j] = m; r.l[j] = (__bf16)r2;
+    }
+    return r;
+}
+
+// image build: one thread per (fragment group, lane, j); idx = canonical parameter offset or -1
+__global__ void k_pack_bf16(unsigned short* __restrict__ img, const int* __restrict__ idx, const float* __restrict__ P, int n)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int fg = t >> 9, lane = (t >> 3) & 63, j = t & 7;
+    const int k = idx[t];
+    const float x = k >= 0 ? P[k] : 0.f;
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    const size_t base = ((size_t)fg * 3 * 64 + lane) * 8 + j;
+    img[base] = __builtin_bit_cast(unsigned short, h);
+    img[base + 64 * 8] = __builtin_bit_cast(unsigned short, m);
+    img[base + 128 * 8] = __builtin_bit_cast(unsigned short, l);
+}
+
+struct Frag3 { bf8 h, m, l; };
+__device__ __forceinline__ Frag3 load_frag(const bf8* __restrict__ img, int fg, int lane)
+{
+    const bf8* b = img + (size_t)fg * 3 * 64 + lane;
+    Frag3 f; f.h = b[0]; f.m = b[64]; f.l = b[128];
+    return f;
+}
+__device__ __forceinline__ f4 mfma_b(bf8 a, bf8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// acc[rt] += W[16rt.., block] x  (six bf16 products per output tile)
+__device__ __forceinline__ void mac_block(const Frag3& a0, const Frag3& a1, const B3& x, f4 (&acc)[2])
+{
+    acc[0] = mfma_b(a0.h, x.h, acc[0]); acc[1] = mfma_b(a1.h, x.h, acc[1]);
+    acc[0] = mfma_b(a0.h, x.m, acc[0]); acc[1] = mfma_b(a1.h, x.m, acc[1]);
+    acc[0] = mfma_b(a0.m, x.h, acc[0]); acc[1] = mfma_b(a1.m, x.h, acc[1]);
+    acc[0] = mfma_b(a0.h, x.l, acc[0]); acc[1] = mfma_b(a1.h, x.l, acc[1]);
+    acc[0] = mfma_b(a0.l, x.h, acc[0]); acc[1] = mfma_b(a1.l, x.h, acc[1]);
+    acc[0] = mfma_b(a0.m, x.m, acc[0]); acc[1] = mfma_b(a1.m, x.m, acc[1]);
+}
+
+// static schedule (see FwdSched): step s multiplies weight block blk[s] with input block xs[s]
+template <int CQ>
+struct FwdSchedB {
+    static constexpr int CB = CQ / 2;
+    static constexpr int NSTEP = 10 + 5 * CB;
+    static constexpr int XE = 0, XC = 3, XH = 3 + CB;      // input block slots: e (3), c (CB), h (1, transient)
+    int blk[NSTEP], xs[NSTEP], bnd[NSTEP], lay[NSTEP];
+    constexpr FwdSchedB() : blk{}, xs{}, bnd{}, lay{}
+    {
+        typedef MlpFwdImgB<CQ> I;
+        int s = 0;
+        for (int l = 0; l < 5; ++l) {
+            if (l == 0 || l == 3) { const int b0 = l == 0 ? I::W0E : I::W3E; for (int b = 0; b < 3; ++b) { blk[s] = b0 + b; xs[s] = XE + b; lay[s] = l; bnd[s] = 0; ++s; } }
+            if (l != 0) { blk[s] = l == 3 ? I::W3H : I::W(l); xs[s] = XH; lay[s] = l; bnd[s] = 0; ++s; }
+            bnd[s - 1] = 1;
+            for (int b = 0; b < CB; ++b) { blk[s] = I::F(l) + b; xs[s] = XC + b; lay[s] = l; bnd[s] = 0; ++s; }
+            bnd[s - 1] = 2;
+        }
+    }
+};
+
+// MLP::forward (reference src/models/MLP.cpp:76-102) on the bf16 matrix cores; same results as mlp_forward to fp32 rounding
+template <int CQ>
+__device__ __forceinline__ void mlp_forward_bf16(const bf8* __restrict__ img, const float* __restrict__ imgf, int lane, Act<CQ>& A)
+{
+    typedef MlpFwdImgB<CQ> I;
+    constexpr FwdSchedB<CQ> S{};
+    const int g = lane >> 4;
+    B3 X[S.XH + 1];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) X[S.XE + b] = split_block(A.xe[2 * b], A.xe[2 * b + 1]);
+#pragma unroll
+    for (int b = 0; b < S.CB; ++b) X[S.XC + b] = split_block(A.xc[2 * b], A.xc[2 * b + 1]);
+    Frag3 ring[2][2];
+    ring[0][0] = load_frag(img, 2 * S.blk[0], lane); ring[0][1] = load_frag(img, 2 * S.blk[0] + 1, lane);
+    unsigned long long mask = 0;
+    f4 acc[2];
+    load_bias(imgf + I::P_B, g, acc);
+#pragma unroll
+    for (int s = 0; s < S.NSTEP; ++s) {
+        if (s + 1 < S.NSTEP) { ring[(s + 1) & 1][0] = load_frag(img, 2 * S.blk[s + 1], lane); ring[(s + 1) & 1][1] = load_frag(img, 2 * S.blk[s + 1] + 1, lane); }
+        __builtin_amdgcn_sched_barrier(0);
+        mac_block(ring[s & 1][0], ring[s & 1][1], X[S.xs[s]], acc);
+        if (S.bnd[s] == 1) {
+            mask |= (unsigned long long)relu_mask(acc) << (8 * S.lay[s]);
+            f4 bc[2]; load_bias(imgf + I::P_BC + 32 * S.lay[s], g, bc); acc[0] += bc[0]; acc[1] += bc[1];
+        } else if (S.bnd[s] == 2) {
+            const int l = S.lay[s];
+            A.h[l][0] = acc[0]; A.h[l][1] = acc[1];
+            if (l < 4) { X[S.XH] = split_block(acc[0], acc[1]); load_bias(imgf + I::P_B + 32 * (l + 1), g, acc); }
+        }
+    }
+    A.mask = mask;
+}
+
+// K2 (bf16-split form): same contract as decode_fwd_body for the MLP decoders (WHICH = 1, 2, 3)
+template <int WHICH, int NW = 8>
+__device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, int nb)
+{
+    constexpr int CQ = WHICH == 2 ? 4 : 2;
+    constexpr int OD = WHICH == 3 ? 4 : 1;
+    typedef MlpFwdImgB<CQ> I;
+    extern __shared__ __attribute__((aligned(16))) f4 smem[];
+    const f4* src = reinterpret_cast<const f4*>(A.img16);
+    for (int i = threadIdx.x; i < I::TOTAL_F / 4; i += 64 * NW) smem[i] = src[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const bf8* img = reinterpret_cast<const bf8*>(smem);
+    const float* imgf = reinterpret_cast<const float*>(smem);
+    const int ntasks = (A.M + 15) >> 4;
+    for (int task = bid * NW + wave; task < ntasks; task += nb * NW) {
+        asm volatile("" ::: "memory");
+        const int m = task * 16 + j;
+        const int mm = min(m, A.M - 1);
+        float px, py, pz, zz; int n;
+        sample_point(A, mm, px, py, pz, zz, n);
+        Tri T;
+        tri_setup(A.grid, A.bound, px, py, pz, T);
+        Act<CQ> C;
+        tri_gather(A.grid, T, g, C.xc[0], C.xc[1]);
+        if constexpr (WHICH == 2) {
+            Tri Tm;
+            tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
+            tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
+        }
+        f4 dummy[6];
+        embed<false>(imgf + I::P_BM, g, px, py, pz, C.xe, dummy);
+        mlp_forward_bf16<CQ>(img, imgf, lane, C);
+        float out[OD];
+        mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);
+        if (m < A.M) {
+            if (g == 0) {
+                if constexpr (OD == 4) *reinterpret_cast<f4*>(A.out + (size_t)m * 4) = (f4){out[0], out[1], out[2], out[OD - 1]};
+                else A.out[m] = out[0];
+            }
+            if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_decode_fwd_multi_bf16(MultiArgs MA)
+{
+    int r = 0;
+    while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
+    const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];
+    const int bid = blockIdx.x - b0, nb = MA.wg_end[r] - b0;
+    switch (MA.which[r]) {
+    case 0: decode_fwd_body<0, 8>(MA.a[r], bid, nb); break;
+    case 1: decode_fwd_bf16_body<1, 8>(MA.a[r], bid, nb); break;
+    case 2: decode_fwd_bf16_body<2, 8>(MA.a[r], bid, nb); break;
+    default: decode_fwd_bf16_body<3, 8>(MA.a[r], bid, nb); break;
+    }
+}

@@ -432,6 +432,7 @@ struct DecArgs {
     float bound[6];
     GridD grid, grid_mid;
     const f4* img;            // forward image (global)
+    const void* img16;        // bf16 3-piece forward image (nsk_bf16.h) or nullptr
     const f4* bimg;           // backward image (global)
     int img_f4;               // forward image size in f4
     float* out;               // occupancy [M] (which<3) or rgb4 [M][4] (color)

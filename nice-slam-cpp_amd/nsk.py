@@ -17,7 +17,7 @@ GROUP_DECODERS, GROUP_COARSE, GROUP_MIDDLE, GROUP_FINE, GROUP_COLOR, GROUP_CAMER
 # every symbol include/nsk.h declares
 SYMBOLS = (
     "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
-    "nsk_set_render_opts", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask",
+    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask",
     "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
@@ -141,6 +141,9 @@ class Context:
         _chk(lib().nsk_set_render_opts(self.h, n_samples, n_surface, int(lindisp), C.c_float(perturb), int(occupancy),
                                        C.c_uint64(seed)))
         self.n_samples, self.n_surface = n_samples, n_surface
+
+    def set_matmul_mode(self, mode):
+        _chk(lib().nsk_set_matmul_mode(self.h, int(mode)))
 
     def sync(self):
         _chk(lib().nsk_sync(self.h))

@@ -328,3 +328,25 @@ def test_tracking_steps_match_oracle(oracle32, oracle64):
     e_p, e_p_ref = rel_l2(cam.cpu().numpy(), cam64), rel_l2(cam32, cam64)
     assert e_p < max(TOL, 3 * e_p_ref), (e_p, e_p_ref)
     print("tracking: grad err hip %.2e oracle32 %.2e | pose err hip %.2e oracle32 %.2e" % (e_g, e_g_ref, e_p, e_p_ref))
+
+
+@pytest.mark.parametrize("stage", ["fine", "color"])
+def test_forward_bf16_split_mode_matches_oracle(stage, oracle32, oracle64):
+    """matmul mode 1: fp32 operands as three bf16 pieces, six bf16 MFMAs per product -- must stay inside the same 1e-4
+    contract, and as close to the fp64 truth as the plain fp32 path"""
+    sc = _scene()
+    rays = scenes.make_rays(4, 100, sc["bound"], n_frames=2, zero_frac=0.1)
+    gd = rays["gt_depth"]
+    ref = oracle32.render_forward(oracle32.opts(sc["bound"]), sc["grids"], sc["decoders"], stage, rays["rays_o"], rays["rays_d"], gd)
+    ref64 = oracle64.render_forward(oracle64.opts(sc["bound"]), sc["grids"], sc["decoders"], stage, rays["rays_o"], rays["rays_d"], gd)
+    errs = {}
+    for mode in (0, 1):
+        ctx = make_ctx(sc)
+        ctx.set_matmul_mode(mode)
+        rgb, depth, var, w = ctx.render_forward(stage, cu(rays["rays_o"]), cu(rays["rays_d"]), cu(gd))
+        ctx.sync()
+        assert rel_l2(depth.cpu().numpy(), ref["depth"]) < TOL and rel_l2(w.cpu().numpy(), ref["weights"]) < TOL
+        if stage == "color":
+            assert rel_l2(rgb.cpu().numpy(), ref["rgb"]) < TOL
+        errs[mode] = rel_l2(w.cpu().numpy(), ref64["weights"])
+    assert errs[1] < 3 * errs[0] + 1e-6, errs

@@ -418,7 +418,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     CHK(set_lds(k_decode_fwd<0>, fwd_img_floats(0) * 4)); CHK(set_lds(k_decode_fwd<1>, fwd_img_floats(1) * 4));
     CHK(set_lds(k_decode_fwd<2>, fwd_img_floats(2) * 4)); CHK(set_lds(k_decode_fwd<3>, fwd_img_floats(3) * 4));
 #define SETB(W) \
-    CHK(set_lds(k_decode_bwd<W, false, false>, bwd_lds_bytes(W, false))); CHK(set_lds(k_decode_bwd<W, false, true>, bwd_lds_bytes(W, false))); \
+    CHK(set_lds(k_decode_bwd<W, false>, bwd_lds_bytes(W, false))); CHK(set_lds(k_decode_bwd<W, true>, bwd_lds_bytes(W, false))); \
     CHK(set_lds(k_decode_bwd_train<W, false>, bwd_lds_bytes(W, true))); CHK(set_lds(k_decode_bwd_train<W, true>, bwd_lds_bytes(W, true)));
     SETB(0) SETB(1) SETB(2) SETB(3)
 #undef SETB
@@ -840,7 +840,7 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     ProfScope ps(c, names[w + (train ? 4 : 0)]);
 #define LB(W) \
     if (train) { if (rays) k_decode_bwd_train<W, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd_train<W, false><<<grid, 512, lds, c->stream>>>(A); } \
-    else { if (rays) k_decode_bwd<W, false, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd<W, false, false><<<grid, 512, lds, c->stream>>>(A); }
+    else { if (rays) k_decode_bwd<W, true><<<grid, 512, lds, c->stream>>>(A); else k_decode_bwd<W, false><<<grid, 512, lds, c->stream>>>(A); }
     switch (w) {
     case 0: LB(0) break;
     case 1: LB(1) break;

@@ -758,142 +758,36 @@ __device__ __forceinline__ void tri_grad_p(const GridD& G, const Tri& T, int g, 
     for (int k = 0; k < 3; ++k) gp[k] += gi[k] * T.gmul[k];
 }
 
-// ------------------------------------------------------------------------------------------------------
-// per-workgroup accumulation of decoder weight gradients: dW[o][x] += sum_samples G[o][s] X[x][s].
-// G (32 rows) and a 16-row chunk of X are transposed through per-wave LDS scratch ([row][20]) and contracted
-// over the tile's 16 samples with four MFMA steps; the 16x16 result is added into the workgroup's LDS
-// accumulator (canonical parameter layout) with ds_add_f32.
-// ------------------------------------------------------------------------------------------------------
-#define TG_LD 20
-// write one D-layout quad (16 feature rows x 16 samples) transposed: dst[row][sample]
-__device__ __forceinline__ void wg_put_quad(float* __restrict__ dst, int lane, f4 x)
-{
-    const int j = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dst[(4 * g + i) * TG_LD + j] = x[i];
-}
-
-// D[o][x] for G row tile rt (rows 16rt..) and the X chunk currently in tx
-__device__ __forceinline__ f4 wg_outer(const float* __restrict__ tg, const float* __restrict__ tx, int rt, int lane)
-{
-    const int r = lane & 15, sq = lane >> 4;
-    f4 a = *reinterpret_cast<const f4*>(tg + (16 * rt + r) * TG_LD + 4 * sq);
-    f4 b = *reinterpret_cast<const f4*>(tx + r * TG_LD + 4 * sq);
-    f4 d = (f4)(0.f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) d = mfma4(a[i], b[i], d);
-    return d;
-}
-
-// add tile D (rows o = 16rt+4g+i, col x = lane&15) into acc[base + o*ld + col0 + x] for o < rows, x < cols
-__device__ __forceinline__ void wg_add(float* __restrict__ acc, int base, int ld, int col0, int rows, int cols, int rt,
-                                       int lane, f4 d)
-{
-    const int x = lane & 15, g = lane >> 4;
-    if (x < cols && acc) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int o = 16 * rt + 4 * g + i;
-            if (o < rows) atomicAdd(acc + base + o * ld + col0 + x, d[i]);
-        }
-    }
-}
 #ifdef NSK_EXPERIMENT
 #define NSK_DBG(A, bit) (((A).flags >> (bit)) & 1u)
 #else
 #define NSK_DBG(A, bit) 0u
 #endif
 
-// one X chunk against both G row tiles
-__device__ __forceinline__ void wg_chunk(float* __restrict__ acc, int base, int ld, int col0, int rows, int cols,
-                                         const float* __restrict__ tg, float* __restrict__ tx, int lane, f4 xq)
-{
-    wg_put_quad(tx, lane, xq);
-    lds_fence();
-    f4 d0 = wg_outer(tg, tx, 0, lane);
-    f4 d1 = (f4)(0.f);
-    if (rows > 16) d1 = wg_outer(tg, tx, 1, lane);
-    lds_fence();
-    wg_add(acc, base, ld, col0, rows, cols, 0, lane, d0);
-    if (rows > 16) wg_add(acc, base, ld, col0, rows, cols, 1, lane, d1);
-}
-
-// row sums over the tile's samples: acc[base + o] += sum_s G[o][s]
-__device__ __forceinline__ void wg_add_rowsum(float* __restrict__ acc, int base, int rows, const float* __restrict__ tg,
-                                              int lane)
-{
-    const int r = lane & 15, sq = lane >> 4;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        if (16 * rt < rows) {
-            f4 a = *reinterpret_cast<const f4*>(tg + (16 * rt + r) * TG_LD + 4 * sq);
-            f4 d = (f4)(0.f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d = mfma4(a[i], 1.0f, d);
-            if (r == 0 && acc) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int o = 16 * rt + 4 * sq + i;
-                    if (o < rows) atomicAdd(acc + base + o, d[i]);
-                }
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void wg_zero_tg(float* __restrict__ tg, int lane)
-{
-    for (int r = lane; r < 32 * TG_LD; r += 64) tg[r] = 0.f;
-}
-
 // ------------------------------------------------------------------------------------------------------
-// K4: decoder backward over 16-sample tiles.
-//   TRAIN=false: "light" backward of a frozen decoder from the saved ReLU bits: g_out -> g_c (-> grid
-//                gradient scatter) [-> g_p for NSK_GRAD_RAYS].  LDS holds the backward image.
-//   TRAIN=true : recompute the forward (forward image in LDS; fine: streamed from L2 because image +
-//                accumulator exceed 160 KiB), then the same chain with backward fragments streamed from L2,
-//                plus all parameter gradients accumulated per workgroup in LDS and flushed once with atomics.
+// K4 (frozen decoders): backward over 16-sample tiles from the ReLU bits the forward saved:
+// g_out -> chain of transposed products -> g_c (-> run-deduplicated scatter into the grid gradient)
+// [-> g_p for NSK_GRAD_RAYS: embedding and trilinear derivatives].  LDS holds the backward image.
+// Trainable decoders use decode_bwd_train_body (nsk_train.h).
 // ------------------------------------------------------------------------------------------------------
-template <int WHICH, bool TRAIN, bool RAYS>
+template <int WHICH, bool RAYS>
 __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int nb)
 {
     constexpr bool XYZ = WHICH != 0;
-    constexpr int CQ = WHICH == 2 ? 4 : 2;
     constexpr int OD = WHICH == 3 ? 4 : 1;
-    constexpr bool NEED_E = XYZ && (TRAIN || RAYS);
-    constexpr bool FWD_LDS = TRAIN && WHICH != 2;
-    typedef MlpFwdImg<CQ> FI;
-    constexpr int FWD_F = XYZ ? FI::TOTAL : CoarseFwdImg::TOTAL;
-    constexpr int BWD_F = XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL;
-    constexpr int IMG_F = TRAIN ? (FWD_LDS ? FWD_F : 0) : BWD_F;
-    constexpr DecLayoutDev L = dec_layout_dev<WHICH>();
-    constexpr int NPAR = L.total;
-    constexpr int NPAR4 = TRAIN ? ((NPAR + 3) & ~3) : 0;
+    constexpr bool NEED_E = XYZ && RAYS;
+    constexpr int IMG_F = XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL;
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-    // LDS carve: [image][dW accumulator (TRAIN)][per-wave scratch 3840 B]
     float* smf = reinterpret_cast<float*>(smem);
-    float* dacc = smf + IMG_F;
-    float* scratch = dacc + NPAR4 + wave * 960;
-    {
-        const f4* src = TRAIN ? A.img : A.bimg;
-        for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = src[i];
-        for (int i = threadIdx.x; i < NPAR4; i += 512) dacc[i] = 0.f;
-    }
+    float* scratch = smf + IMG_F + wave * 960;                  // per-wave scatter scratch (3840 B)
+    for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.bimg[i];
     __syncthreads();
-    const f4* fimg = FWD_LDS ? smem : A.img;
-    const float* fimgf = reinterpret_cast<const float*>(fimg);
-    const f4* bimg = TRAIN ? A.bimg : smem;
-    const float* bimgf = reinterpret_cast<const float*>(bimg);
+    const f4* bimg = smem;
+    const float* bimgf = reinterpret_cast<const float*>(smem);
     const float* Bm = nullptr;
-    if constexpr (XYZ) Bm = TRAIN ? fimgf + FI::P_BM : bimgf + MlpBwdImg::P_BM;
-    const float* Wo = TRAIN ? (XYZ ? fimgf + FI::P_WO : fimgf + CoarseFwdImg::P_WO)
-                            : (XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO);
-    float* tg = scratch;                  // [32][20]
-    float* tx = scratch + 32 * TG_LD;     // [16][20]
-    float* const dacc_real = dacc;
-    if (NSK_DBG(A, 8)) dacc = nullptr;
-    const bool skip_wg = NSK_DBG(A, 10);
+    if constexpr (XYZ) Bm = bimgf + MlpBwdImg::P_BM;
+    const float* Wo = XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO;
 
     const int ntasks = (A.M + 15) >> 4;
     for (int task = bid * 8 + wave; task < ntasks; task += nb * 8) {
@@ -905,7 +799,6 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         sample_point(A, mm, px, py, pz, zz, n);
         Tri T;
         tri_setup(A.grid, A.bound, px, py, pz, T);
-        // upstream gradient of this decoder's output
         float gout[OD];
         {
             f4 gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
@@ -913,33 +806,10 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
             else gout[0] = gr[3];
         }
-        // activations (TRAIN) or saved ReLU bits (frozen)
-        Act<CQ> C;
-        ActC CC;
+        const unsigned long long mask = A.masks[(size_t)mm * 4 + g];
         f4 xcos[6];
-        unsigned long long mask;
-        if constexpr (TRAIN) {
-            if constexpr (XYZ) {
-                tri_gather(A.grid, T, g, C.xc[0], C.xc[1]);
-                if constexpr (WHICH == 2) {
-                    Tri Tm;
-                    tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
-                    tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
-                }
-                embed<true>(Bm, g, px, py, pz, C.xe, xcos);
-                mlp_forward<CQ>(fimg, lane, C);
-                mask = C.mask;
-            } else {
-                tri_gather(A.grid, T, g, CC.xc[0], CC.xc[1]);
-                coarse_forward(fimg, lane, CC);
-                mask = CC.mask;
-            }
-        } else {
-            mask = A.masks[(size_t)mm * 4 + g];
-            if constexpr (NEED_E) { f4 e[6]; embed<true>(Bm, g, px, py, pz, e, xcos); }
-        }
-        // g_h4 = Wo^T g_out
-        f4 gh[2];
+        if constexpr (NEED_E) { f4 e[6]; embed<true>(Bm, g, px, py, pz, e, xcos); }
+        f4 gh[2];                                                // g_h4 = Wo^T g_out
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -949,22 +819,6 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                 for (int o = 0; o < OD; ++o) s += Wo[32 * o + 16 * r + 4 * g + i] * gout[o];
                 gh[r][i] = s;
             }
-        if (TRAIN && !skip_wg) {   // d output_linear
-            wg_zero_tg(tg, lane);
-            lds_fence();
-            if (g == 0) {
-#pragma unroll
-                for (int o = 0; o < OD; ++o) tg[o * TG_LD + j] = gout[o];
-            }
-            lds_fence();
-            wg_add_rowsum(dacc, L.obo, OD, tg, lane);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                f4 hq;
-                if constexpr (XYZ) hq = C.h[4][q]; else hq = CC.h[4][q];
-                wg_chunk(dacc, L.oWo, 32, 16 * q, OD, 16, tg, tx, lane, hq);
-            }
-        }
         f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
         f4 ge[6];
 #pragma unroll
@@ -977,44 +831,6 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
-            if (TRAIN && !skip_wg) {
-                if constexpr (XYZ) {       // d fc[l] = g_h c^T, d fc_bias[l] = sum g_h
-                    wg_put_quad(tg, lane, gh[0]);
-                    wg_put_quad(tg + 16 * TG_LD, lane, gh[1]);
-                    lds_fence();
-                    wg_add_rowsum(dacc, L.oFb[l], 32, tg, lane);
-#pragma unroll
-                    for (int q = 0; q < CQ; ++q) wg_chunk(dacc, L.oFw[l], 16 * CQ, 16 * q, 32, 16, tg, tx, lane, C.xc[q]);
-                }
-                // d pts_linear[l] = g_a x^T, bias = sum g_a
-                wg_put_quad(tg, lane, ga[0]);
-                wg_put_quad(tg + 16 * TG_LD, lane, ga[1]);
-                lds_fence();
-                wg_add_rowsum(dacc, L.ob[l], 32, tg, lane);
-                const int nx = L.in_dim[l];
-                if constexpr (XYZ) {
-                    if (l == 0 || l == 3) {
-#pragma unroll
-                        for (int q = 0; q < 6; ++q)
-                            wg_chunk(dacc, L.oW[l], nx, 16 * q, 32, (NSK_E - 16 * q) < 16 ? (NSK_E - 16 * q) : 16, tg, tx, lane, C.xe[q]);
-                    }
-                    if (l != 0) {
-                        const int col0 = l == 3 ? NSK_E : 0;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) wg_chunk(dacc, L.oW[l], nx, col0 + 16 * q, 32, 16, tg, tx, lane, C.h[l > 0 ? l - 1 : 0][q]);
-                    }
-                } else {
-                    if (l == 0 || l == 3) {
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) wg_chunk(dacc, L.oW[l], nx, 16 * q, 32, 16, tg, tx, lane, CC.xc[q]);
-                    }
-                    if (l != 0) {
-                        const int col0 = l == 3 ? 32 : 0;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) wg_chunk(dacc, L.oW[l], nx, col0 + 16 * q, 32, 16, tg, tx, lane, CC.h[l > 0 ? l - 1 : 0][q]);
-                    }
-                }
-            }
             if constexpr (XYZ) {
                 if constexpr (NEED_E) {
                     if (l == 3) gemm_e(bimg, MlpBwdImg::W3ET, lane, ga, ge);
@@ -1036,23 +852,12 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                 }
             }
         }
-        // embedding backward: g_s = g_e * cos(pB);  dB = p^T g_s;  g_p += g_s B^T
-        float gp[3] = {0.f, 0.f, 0.f};
-        if constexpr (NEED_E) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) ge[q] *= xcos[q];
-            if (TRAIN && !skip_wg) {
-                wg_zero_tg(tg, lane);
-                lds_fence();
-                if (g == 0) { tg[0 * TG_LD + j] = valid ? px : 0.f; tg[1 * TG_LD + j] = valid ? py : 0.f; tg[2 * TG_LD + j] = valid ? pz : 0.f; }
-                lds_fence();
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-                    wg_chunk(dacc, L.oB, NSK_E, 16 * q, 3, (NSK_E - 16 * q) < 16 ? (NSK_E - 16 * q) : 16, tg, tx, lane, ge[q]);
-            }
-            if constexpr (RAYS) {
+        if constexpr (RAYS) {       // g_p through the embedding (g_e * cos(pB)) B^T and through the trilinear lookup
+            float gp[3] = {0.f, 0.f, 0.f};
+            if constexpr (NEED_E) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
+                    ge[q] *= xcos[q];
                     f4 b0 = *reinterpret_cast<const f4*>(Bm + 16 * q + 4 * g);
                     f4 b1 = *reinterpret_cast<const f4*>(Bm + 96 + 16 * q + 4 * g);
                     f4 b2 = *reinterpret_cast<const f4*>(Bm + 192 + 16 * q + 4 * g);
@@ -1060,8 +865,6 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                     for (int i = 0; i < 4; ++i) { gp[0] += ge[q][i] * b0[i]; gp[1] += ge[q][i] * b1[i]; gp[2] += ge[q][i] * b2[i]; }
                 }
             }
-        }
-        if constexpr (RAYS) {
             tri_grad_p(A.grid, T, g, gc, gp);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { gp[k] += __shfl_xor(gp[k], 16); gp[k] += __shfl_xor(gp[k], 32); }
@@ -1075,14 +878,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         }
         if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) scatter_tile(A.grid, T, gc, lane, valid, scratch);
     }
-    if constexpr (TRAIN) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < NPAR; i += 512) {
-            float v = dacc_real[i];
-            if (v != 0.f) atomicAdd(A.g_dec + i, v);
-        }
-    }
 }
 
-template <int WHICH, bool TRAIN, bool RAYS>
-__global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A) { decode_bwd_body<WHICH, TRAIN, RAYS>(A, blockIdx.x, gridDim.x); }
+template <int WHICH, bool RAYS>
+__global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A) { decode_bwd_body<WHICH, RAYS>(A, blockIdx.x, gridDim.x); }

@@ -399,13 +399,13 @@ __global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
     const int bid = blockIdx.x - b0, nb = MA.wg_end[r] - b0;
     const int sel = MA.which[r] * 2 + (MA.train[r] ? 1 : 0);
     switch (sel) {
-    case 0: decode_bwd_body<0, false, RAYS>(MA.a[r], bid, nb); break;
+    case 0: decode_bwd_body<0, RAYS>(MA.a[r], bid, nb); break;
     case 1: decode_bwd_train_body<0, RAYS>(MA.a[r], bid, nb); break;
-    case 2: decode_bwd_body<1, false, RAYS>(MA.a[r], bid, nb); break;
+    case 2: decode_bwd_body<1, RAYS>(MA.a[r], bid, nb); break;
     case 3: decode_bwd_train_body<1, RAYS>(MA.a[r], bid, nb); break;
-    case 4: decode_bwd_body<2, false, RAYS>(MA.a[r], bid, nb); break;
+    case 4: decode_bwd_body<2, RAYS>(MA.a[r], bid, nb); break;
     case 5: decode_bwd_train_body<2, RAYS>(MA.a[r], bid, nb); break;
-    case 6: decode_bwd_body<3, false, RAYS>(MA.a[r], bid, nb); break;
+    case 6: decode_bwd_body<3, RAYS>(MA.a[r], bid, nb); break;
     default: decode_bwd_train_body<3, RAYS>(MA.a[r], bid, nb); break;
     }
 }

@@ -87,6 +87,14 @@ int nsk_grid_grad_download(nsk_ctx* ctx, int level, float* h_czyx);
  * optimiser parameters; NULL = all voxels.  Gradients of unmarked voxels are discarded. */
 int nsk_set_mask(nsk_ctx* ctx, int level, const uint8_t* h_mask_zyx);
 
+/* Mapper::get_mask_from_c2w (src/Mapper.cpp:42-130, intended semantics): builds the frustum mask of `level` on the device from
+ * a depth image (d_depth [H][W], device) and the current pose h_c2w (16 floats, row-major [4][4]) and installs it like
+ * nsk_set_mask; h_mask_out [Z*Y*X] (host, may be NULL) receives a copy.  A voxel is kept if its centre projects inside the image
+ * with 0 <= depth_along_-z <= sampled_depth + 0.5 (zero depths count as the maximum sampled depth) or lies within 0.5 m of the
+ * camera centre; grid_coarse keeps every voxel. */
+int nsk_frustum_mask(nsk_ctx* ctx, int level, const float* d_depth, int H, int W, float fx, float fy, float cx, float cy,
+                     const float h_c2w[16], uint8_t* h_mask_out);
+
 /* ---- decoders (src/models/MLP.cpp:3-49,104-138; src/models/GaussianFFT.cpp:3-8) -------------------------- */
 /* packed parameter order (row-major [out,in] as torch::nn::Linear):
  *   middle/fine/color: B[3][93], pts_linear[0..4].{weight,bias}, fc[0..4].{weight,bias}, output_linear.{weight,bias}

@@ -301,6 +301,65 @@ __global__ __launch_bounds__(256) void k_raw2outputs(int N, int S, int occupancy
     if (lane == 0) { depth[n] = D; var[n] = V; rgb[3 * n] = cr; rgb[3 * n + 1] = cg; rgb[3 * n + 2] = cb; }
 }
 
+// Frustum voxel mask (next row N2): Mapper::get_mask_from_c2w, reference src/Mapper.cpp:42-130 (intended semantics, D21/D22):
+// pass 1 projects every voxel centre into the frame, samples the depth image bilinearly (cv::remap INTER_LINEAR, zero border)
+// and takes the maximum sampled depth; pass 2 applies the in-image / depth / near-camera tests.
+__device__ __forceinline__ void voxel_point(const float* b, int Z, int Y, int X, int v, float (&p)[3])
+{
+    int ix = v % X, iy = (v / X) % Y, iz = v / (X * Y);
+    p[0] = add_rn(b[0], mul_rn(sub_rn(b[1], b[0]), linspace01(ix, X)));
+    p[1] = add_rn(b[2], mul_rn(sub_rn(b[3], b[2]), linspace01(iy, Y)));
+    p[2] = add_rn(b[4], mul_rn(sub_rn(b[5], b[4]), linspace01(iz, Z)));
+}
+struct FrustumArgs { float bound[6]; float w2c[16]; float cam[3]; int Z, Y, X, H, W; float fx, fy, cx, cy; };
+__global__ void k_frustum_pass1(FrustumArgs A, const float* __restrict__ img, float* __restrict__ dep, float* __restrict__ zz,
+                                uint8_t* __restrict__ inimg, unsigned int* __restrict__ dmax_bits)
+{
+    const int n = A.Z * A.Y * A.X;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    float d = 0.f;
+    if (v < n) {
+        float p[3], cam[3];
+        voxel_point(A.bound, A.Z, A.Y, A.X, v, p);
+        for (int a = 0; a < 3; ++a)
+            cam[a] = add_rn(add_rn(add_rn(mul_rn(A.w2c[4 * a], p[0]), mul_rn(A.w2c[4 * a + 1], p[1])), mul_rn(A.w2c[4 * a + 2], p[2])), A.w2c[4 * a + 3]);
+        cam[0] = -cam[0];
+        const float z = add_rn(cam[2], 1e-5f);
+        const float u = div_rn(add_rn(mul_rn(A.fx, cam[0]), mul_rn(A.cx, cam[2])), z);
+        const float w = div_rn(add_rn(mul_rn(A.fy, cam[1]), mul_rn(A.cy, cam[2])), z);
+        const float x0 = floorf(u), y0 = floorf(w);
+        const float ax = sub_rn(u, x0), ay = sub_rn(w, y0);
+        const int ix = (int)x0, iy = (int)y0;
+        float s = 0.f;
+        for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+            int x = ix + dx, y = iy + dy;
+            if (x < 0 || x >= A.W || y < 0 || y >= A.H) continue;
+            s = add_rn(s, mul_rn(mul_rn(dx ? ax : sub_rn(1.f, ax), dy ? ay : sub_rn(1.f, ay)), img[(size_t)y * A.W + x]));
+        }
+        d = s;
+        dep[v] = d; zz[v] = z;
+        inimg[v] = (u < (float)A.W && u > 0.f && w < (float)A.H && w > 0.f) ? 1 : 0;
+    }
+    float m = wave_max(fmaxf(d, 0.f));
+    if ((threadIdx.x & 63) == 0) atomicMax(dmax_bits, __float_as_uint(m));     // non-negative floats order like their bit patterns
+}
+__global__ void k_frustum_pass2(FrustumArgs A, const float* __restrict__ dep, const float* __restrict__ zz, const uint8_t* __restrict__ inimg,
+                                const unsigned int* __restrict__ dmax_bits, uint8_t* __restrict__ mask)
+{
+    const int n = A.Z * A.Y * A.X;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float dmax = __uint_as_float(*dmax_bits);
+    const float d = dep[v] == 0.f ? dmax : dep[v];
+    const float nz = -zz[v];
+    int m = inimg[v] && (0.f <= nz) && (nz <= add_rn(d, 0.5f));
+    float p[3];
+    voxel_point(A.bound, A.Z, A.Y, A.X, v, p);
+    const float dx = sub_rn(p[0], A.cam[0]), dy = sub_rn(p[1], A.cam[1]), dz = sub_rn(p[2], A.cam[2]);
+    if (add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)) < 0.25f) m = 1;
+    mask[v] = (uint8_t)m;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------
@@ -342,7 +401,8 @@ struct nsk_ctx {
     DecState dec[4];
     float* slab = nullptr; size_t slab_n = 0;
     Workspace ws;
-    float* scal = nullptr;       // [0] gt max, [1] median threshold, [2] loss
+    float* scal = nullptr;       // [0] gt max, [1] median threshold, [2] loss, [4] frustum max depth (bits)
+    void* fr_tmp = nullptr; size_t fr_cap = 0;      // nsk_frustum_mask scratch
     int adam_step[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     int matmul_mode = 0;                    // 0 fp32 MFMA, 1 bf16 3-piece split (forward)
@@ -448,7 +508,7 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
         hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv);
         hipFree(c->dec[i].fimg16); hipFree(c->dec[i].fidx16);
     }
-    hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal);
+    hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal); hipFree(c->fr_tmp);
     free_ws(c->ws);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1178,6 +1238,60 @@ static void intr(int mode, float& fx, float& fy, float& cx, float& cy)
 {
     if (mode & 2) { fx = (float)(int)fx; fy = (float)(int)fy; cx = (float)(int)cx; cy = (float)(int)cy; }   // D10
 }
+static void invert4(const float* m, float* inv)          // Gauss-Jordan with partial pivoting, in double
+{
+    double a[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = m[4 * i + j]; a[i][4 + j] = i == j; }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+        for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[p][j]);
+        double d = a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] /= d;
+        for (int r = 0; r < 4; ++r) if (r != c) { double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) inv[4 * i + j] = (float)a[i][4 + j];
+}
+
+extern "C" int nsk_frustum_mask(nsk_ctx* c, int level, const float* d_depth, int H, int W, float fx, float fy, float cx, float cy,
+                                const float h_c2w[16], uint8_t* h_mask_out)
+{
+    if (!c || !which_ok(level) || !d_depth || !h_c2w) return fail("nsk_frustum_mask: bad argument");
+    GridState& G = c->grid[level];
+    if (!G.n) return fail("nsk_frustum_mask: grid level %d not uploaded", level);
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nvox = G.n / 32;
+    if (!G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMalloc(&G.mask, nvox)); }
+    if (level == NSK_COARSE) {                                   // src/Mapper.cpp:54-59
+        HIPCHK(hipMemsetAsync(G.mask, 1, nvox, c->stream));
+    } else {
+        if (nvox > c->fr_cap) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            hipFree(c->fr_tmp);
+            HIPCHK(hipMalloc(&c->fr_tmp, nvox * 9 + 16));
+            c->fr_cap = nvox;
+        }
+        float* dep = reinterpret_cast<float*>(c->fr_tmp); float* zz = dep + nvox;
+        uint8_t* inimg = reinterpret_cast<uint8_t*>(zz + nvox);
+        unsigned int* dmax = reinterpret_cast<unsigned int*>(c->scal + 4);
+        FrustumArgs A;
+        memcpy(A.bound, c->R.bound, sizeof(A.bound));
+        invert4(h_c2w, A.w2c);
+        A.cam[0] = h_c2w[3]; A.cam[1] = h_c2w[7]; A.cam[2] = h_c2w[11];
+        A.Z = G.Z; A.Y = G.Y; A.X = G.X; A.H = H; A.W = W; A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy;
+        HIPCHK(hipMemsetAsync(dmax, 0, 4, c->stream));
+        int blocks = (int)((nvox + 255) / 256);
+        k_frustum_pass1<<<blocks, 256, 0, c->stream>>>(A, d_depth, dep, zz, inimg, dmax);
+        k_frustum_pass2<<<blocks, 256, 0, c->stream>>>(A, dep, zz, inimg, dmax, G.mask);
+        HIPCHK(hipGetLastError());
+    }
+    if (h_mask_out) {
+        HIPCHK(hipMemcpyAsync(h_mask_out, G.mask, nvox, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 extern "C" int nsk_rays_from_pixels(nsk_ctx* c, int n, const int32_t* pi, const int32_t* pj, float fx, float fy, float cx, float cy,
                                     const float* c2w, int mode, float* ro, float* rd)
 {

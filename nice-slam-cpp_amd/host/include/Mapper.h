@@ -1,7 +1,7 @@
 // Same surface as the reference's include/Mapper.h:11-44 for the hot path: Mapper(), run(), optimize_map().
-// keyframe_selection_overlap and get_mask_from_c2w are host bookkeeping outside the accelerated path (SURVEY.md 8,
-// "OUT OF SCOPE" / next rows N2, N3): the window is the most recent keyframes and the frustum mask is an input
-// (set_frustum_mask) that defaults to "all voxels".
+// get_mask_from_c2w (next row N2) runs on the device (nsk_frustum_mask) when mapping.frustum_feature_selection is set, except on
+// levels where the caller installed its own mask with set_frustum_mask.  keyframe_selection_overlap (next row N3) is not built: the window is
+// the most recent keyframes.
 #pragma once
 #include <algorithm>
 #include <iostream>
@@ -47,5 +47,6 @@ class Mapper {
     float BA_cam_lr;
     float w_color_loss;
     bool first_frame = true;
+    bool user_mask[4] = {false, false, false, false};
     uint64_t rng_seed = 0;
 };

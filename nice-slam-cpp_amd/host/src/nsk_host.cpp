@@ -527,6 +527,7 @@ void Mapper::set_frustum_mask(const std::string& key, torch::Tensor mask)
 {
     int level = key == "grid_coarse" ? 0 : key == "grid_middle" ? 1 : key == "grid_fine" ? 2 : key == "grid_color" ? 3 : -1;
     TORCH_CHECK(level >= 0, "unknown grid key ", key);
+    user_mask[level] = true;
     if (!mask.defined()) { check(nsk_set_mask(ctx(), level, nullptr)); return; }
     torch::Tensor m = mask.to(torch::kCPU, torch::kUInt8).contiguous();
     check(nsk_set_mask(ctx(), level, m.data_ptr<uint8_t>()));
@@ -536,7 +537,7 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
                           torch::Tensor gt_cur_c2w, torch::Tensor& cur_c2w, NICE& decoders)     // Mapper.cpp:198-491
 {
     (void)gt_cur_c2w;
-    // window: the most recent keyframes (the overlap ranking of :132-196 is outside the accelerated path) + the current frame (-1)
+    // window: the most recent keyframes (the overlap ranking of :132-196 is next row N3) + the current frame (-1)
     std::vector<int> optimize_frame;
     int nkf = (int)keyframe_vector.size();
     for (int k = std::max(0, nkf - (mapping_window_size - 1)); k < nkf; ++k) optimize_frame.push_back(k);
@@ -548,6 +549,16 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     check(nsk_set_render_opts(ctx(), renderer.N_samples, renderer.N_surface, renderer.lindisp, renderer.perturb, renderer.occupancy, 0));
     nskh::sync_grids(c);
     decoders.sync_to_device();
+    if (frustum_feature_selection) {                                            // :231-281 (depth_mat = cur_gt_depth intended, D21)
+        torch::Tensor dimg = cur_gt_depth.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+        torch::Tensor pose = cur_c2w.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+        DevBuf d_img; d_img.upload(dimg);
+        for (int level = 0; level < 4; ++level)
+            if (!user_mask[level]) check(nsk_frustum_mask(ctx(), level, d_img.p, (int)dimg.size(0), (int)dimg.size(1), fx, fy, cx, cy, pose.data_ptr<float>(), nullptr));
+        check(nsk_sync(ctx()));
+    } else {
+        for (int level = 0; level < 4; ++level) if (!user_mask[level]) check(nsk_set_mask(ctx(), level, nullptr));
+    }
     check(nsk_decoder_set_trainable(ctx(), NSK_FINE, fix_fine ? 0 : 1));                       // :292-301
     check(nsk_decoder_set_trainable(ctx(), NSK_COLOR, fix_color ? 0 : 1));
     check(nsk_adam_reset(ctx()));                                                             // the optimiser is re-created per call (:330)

@@ -135,6 +135,7 @@ int main(int argc, char** argv)
         torch::Tensor fmask = torch::rand({9, 8, 11}) < 0.8;
         mapper.set_frustum_mask("grid_fine", fmask);
         save_npy(out + "map_fine_mask.npy", fmask.to(torch::kFloat32));
+        save_npy(out + "map_depth_img.npy", depth_img); save_npy(out + "map_c2w.npy", c2w);
         std::vector<torch::Tensor> est{c2w.clone(), c2w.clone()};
         torch::Tensor color_before = decoders.color_decoder->packed().clone(), fine_before = decoders.fine_decoder->packed().clone();
         mapper.run(decoders, c, est, color_img, depth_img, c2w, 0, 10);

@@ -17,7 +17,7 @@ GROUP_DECODERS, GROUP_COARSE, GROUP_MIDDLE, GROUP_FINE, GROUP_COLOR, GROUP_CAMER
 # every symbol include/nsk.h declares
 SYMBOLS = (
     "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
-    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask",
+    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask",
     "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
@@ -174,6 +174,19 @@ class Context:
             return
         m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
         _chk(lib().nsk_set_mask(self.h, _stage(level), m.ctypes.data_as(C.c_void_p)))
+
+    @_ordered
+    def frustum_mask(self, level, depth_img, intr, c2w):
+        """Mapper::get_mask_from_c2w on the device; installs the mask and returns it as bool [Z,Y,X]"""
+        import numpy as np
+        H, W = depth_img.shape
+        Cc, Z, Y, X = self._gshape[_stage(level)]
+        m = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(4, 4))
+        out = np.zeros(Z * Y * X, np.uint8)
+        fx, fy, cx, cy = intr
+        _chk(lib().nsk_frustum_mask(self.h, _stage(level), _ptr(depth_img), H, W, C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                    C.c_float(cy), m.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(Z, Y, X).astype(bool)
 
     def decoder_upload(self, which, packed):
         import numpy as np

@@ -803,3 +803,87 @@ NSO_API int nso_num_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Frustum voxel mask ("next" row N2), Mapper::get_mask_from_c2w src/Mapper.cpp:42-130, intended semantics:
+ *   points = meshgrid(linspace(bound) per axis) (D21: float end points), w2c = inverse(c2w) (:62), cam.x *= -1 (:73),
+ *   uv = K cam / (z + 1e-5) (:74-76), depth sampled bilinearly at uv (cv::remap INTER_LINEAR, zero border; :93 --
+ *   D22: the four memcpy's are reversed as written), zero depths replaced by the maximum sampled depth (:104-105),
+ *   mask = 0<u<W & 0<v<H & 0 <= -z <= depth + 0.5 (:102,:109-111; the upstream Python tests -z, the C++ text z),
+ *   OR |p - cam centre|^2 < 0.25 (:121-123).  grid_coarse: all ones (:54-59).
+ * mask layout [Z][Y][X] (the permute of :261).  c2w: 16 floats row-major [4][4].
+ * ------------------------------------------------------------------------------------------ */
+static real bilinear_zero(const real* img, int H, int W, real u, real v)
+{
+    real x0 = r_floor(u), y0 = r_floor(v);
+    real ax = u - x0, ay = v - y0;
+    int ix = (int)x0, iy = (int)y0;
+    real s = 0;
+    for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+        int x = ix + dx, y = iy + dy;
+        if (x < 0 || x >= W || y < 0 || y >= H) continue;
+        s += (dx ? ax : (real)1 - ax) * (dy ? ay : (real)1 - ay) * img[(size_t)y * W + x];
+    }
+    return s;
+}
+
+static void invert_rigid4(const real* m, real* inv)      /* general 4x4 inverse by Gauss-Jordan (c2w need not be orthonormal) */
+{
+    double a[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = m[4 * i + j]; a[i][4 + j] = i == j; }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+        for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
+        double d = a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] /= d;
+        for (int r = 0; r < 4; ++r) if (r != c) { double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) inv[4 * i + j] = (real)a[i][4 + j];
+}
+
+NSO_API void nso_world_to_camera(const real* c2w, real* w2c) { invert_rigid4(c2w, w2c); }
+
+NSO_API int nso_frustum_mask(const real* bound, int Z, int Y, int X, const real* depth_img, int H, int W, real fx, real fy,
+                             real cx, real cy, const real* c2w, int is_coarse, unsigned char* mask /*[Z][Y][X]*/)
+{
+    size_t n = (size_t)Z * Y * X;
+    if (is_coarse) { memset(mask, 1, n); return (int)n; }
+    real w2c[16];
+    invert_rigid4(c2w, w2c);
+    real* dep = (real*)malloc(n * sizeof(real));
+    real* zz = (real*)malloc(n * sizeof(real));
+    unsigned char* inimg = (unsigned char*)malloc(n);
+    real dmax = 0; int first = 1;
+    for (int iz = 0; iz < Z; ++iz) for (int iy = 0; iy < Y; ++iy) for (int ix = 0; ix < X; ++ix) {
+        size_t v = ((size_t)iz * Y + iy) * X + ix;
+        real p[3];
+        p[0] = bound[0] + (bound[1] - bound[0]) * linspace01(ix, X);
+        p[1] = bound[2] + (bound[3] - bound[2]) * linspace01(iy, Y);
+        p[2] = bound[4] + (bound[5] - bound[4]) * linspace01(iz, Z);
+        real cam[3];
+        for (int a = 0; a < 3; ++a) cam[a] = w2c[4 * a] * p[0] + w2c[4 * a + 1] * p[1] + w2c[4 * a + 2] * p[2] + w2c[4 * a + 3];
+        cam[0] = -cam[0];
+        real z = cam[2] + (real)1e-5;
+        real u = (fx * cam[0] + cx * cam[2]) / z, vv = (fy * cam[1] + cy * cam[2]) / z;
+        real d = bilinear_zero(depth_img, H, W, u, vv);
+        dep[v] = d; zz[v] = z;
+        inimg[v] = u < (real)W && u > 0 && vv < (real)H && vv > 0;
+        if (first || d > dmax) { dmax = d; first = 0; }
+    }
+    int cnt = 0;
+    for (int iz = 0; iz < Z; ++iz) for (int iy = 0; iy < Y; ++iy) for (int ix = 0; ix < X; ++ix) {
+        size_t v = ((size_t)iz * Y + iy) * X + ix;
+        real d = dep[v] == 0 ? dmax : dep[v];
+        int m = inimg[v] && (0 <= -zz[v]) && (-zz[v] <= d + (real)0.5);
+        real p[3];
+        p[0] = bound[0] + (bound[1] - bound[0]) * linspace01(ix, X);
+        p[1] = bound[2] + (bound[3] - bound[2]) * linspace01(iy, Y);
+        p[2] = bound[4] + (bound[5] - bound[4]) * linspace01(iz, Z);
+        real dx = p[0] - c2w[3], dy = p[1] - c2w[7], dz = p[2] - c2w[11];
+        if (dx * dx + dy * dy + dz * dz < (real)0.25) m = 1;
+        mask[v] = (unsigned char)m; cnt += m;
+    }
+    free(dep); free(zz); free(inimg);
+    return cnt;
+}

@@ -239,6 +239,25 @@ class Oracle:
                                    self._p(gd), self._p(out))
         return out
 
+    def world_to_camera(self, c2w):
+        m = self.arr(c2w, (4, 4))
+        out = np.zeros((4, 4), self.dt)
+        self.lib.nso_world_to_camera(self._p(m), self._p(out))
+        return out
+
+    def frustum_mask(self, bound, shape_zyx, depth_img, intr, c2w, is_coarse=False):
+        """Mapper::get_mask_from_c2w -> bool [Z,Y,X]"""
+        b = self.arr(bound, (6,))
+        d = self.arr(depth_img)
+        H, W = d.shape
+        Z, Y, X = shape_zyx
+        m = self.arr(c2w, (4, 4))
+        mask = np.zeros((Z, Y, X), np.uint8)
+        R = self.creal
+        fx, fy, cx, cy = intr
+        self.lib.nso_frustum_mask(self._p(b), Z, Y, X, self._p(d), H, W, R(fx), R(fy), R(cx), R(cy), self._p(m), int(is_coarse), self._p(mask))
+        return mask.astype(bool)
+
     def inside_filter(self, bound, rays_o, rays_d, gt_depth):
         b = self.arr(bound, (6,))
         ro, rd, gd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3)), self.arr(gt_depth)

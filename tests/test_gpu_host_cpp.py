@@ -79,6 +79,12 @@ def test_mapper_optimises_grids_and_colour_decoder(dump, oracle32):
         assert np.isfinite(new).all() and np.abs(new - grids[k]).max() > 1e-4, k
     mask = dump["map_fine_mask"] > 0.5
     assert np.array_equal(dump["map_grid_fine"][0][:, ~mask], grids["fine"][:, ~mask])      # frustum mask: unmarked voxels never move
+    # the other levels carry the device frustum mask of the current frame (Mapper.cpp:231-281 -> nsk_frustum_mask)
+    for k in ("middle", "color"):
+        fm = oracle32.frustum_mask(bound, grids[k].shape[1:], dump["map_depth_img"], (40.0, 40.0, 32.0, 24.0), dump["map_c2w"])
+        new = dump["map_grid_" + k][0]
+        assert 0 < fm.sum() < fm.size
+        assert np.array_equal(new[:, ~fm], grids[k][:, ~fm]) and np.abs(new[:, fm] - grids[k][:, fm]).max() > 1e-4, k
     assert float(dump["map_dec_color_delta"][0]) > 1e-5 and float(dump["map_dec_fine_delta"][0]) == 0.0   # fix_fine, !fix_color
     # the Renderer picks the optimised state up without explicit uploads: compare with the oracle on the dumped state
     g2 = dict(grids)

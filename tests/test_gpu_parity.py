@@ -350,3 +350,37 @@ def test_forward_bf16_split_mode_matches_oracle(stage, oracle32, oracle64):
             assert rel_l2(rgb.cpu().numpy(), ref["rgb"]) < TOL
         errs[mode] = rel_l2(w.cpu().numpy(), ref64["weights"])
     assert errs[1] < 3 * errs[0] + 1e-6, errs
+
+
+def test_frustum_mask_matches_oracle(oracle32):
+    """next row N2: Mapper::get_mask_from_c2w (src/Mapper.cpp:42-130) on the device, bit-exact against the restatement"""
+    sc = scenes.make_scene(41)
+    b = sc["bound"]
+    H, W, fx, fy, cx, cy = 120, 160, 80.0, 80.0, 79.5, 59.5
+    rng = np.random.default_rng(3)
+    c2w = scenes.make_camera(rng, b)
+    # depth image of the room walls + a band of zeros (invalid depth)
+    jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    dirs = np.stack([(ii - cx) / fx, -(jj - cy) / fy, -np.ones_like(ii, dtype=np.float64)], -1).reshape(-1, 3) @ c2w[:3, :3].T.astype(np.float64)
+    o = np.broadcast_to(c2w[:3, 3].astype(np.float64), dirs.shape)
+    room = b.astype(np.float64).copy(); room[:, 0] += 0.3; room[:, 1] -= 0.3
+    depth = scenes._ray_box_far(room, o, dirs).reshape(H, W).astype(np.float32)
+    depth[40:50, :] = 0.0
+    ctx = make_ctx(sc)
+    total = 0
+    for level in ("coarse", "middle", "fine", "color"):
+        shape = sc["grids"][level].shape[1:]
+        ref = oracle32.frustum_mask(b, shape, depth, (fx, fy, cx, cy), c2w, is_coarse=(level == "coarse"))
+        got = ctx.frustum_mask(level, cu(depth), (fx, fy, cx, cy), c2w)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), (level, int((got != ref).sum()))
+        if level != "coarse":
+            assert 0 < ref.sum() < ref.size
+        total += int(ref.sum())
+    # the installed mask is what Adam honours: voxels outside never move
+    rays = scenes.make_rays(5, 200, b, n_frames=1)
+    ctx.map_step("color", cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"]), cu(rays["gt_color"]), -1.0, 0.5, True, flags=1)
+    ctx.adam_step([0.0, 0.0, 0.005, 0.005, 0.005, 0.0])
+    fine_mask = oracle32.frustum_mask(b, sc["grids"]["fine"].shape[1:], depth, (fx, fy, cx, cy), c2w)
+    new = ctx.grid_download("fine")
+    assert np.array_equal(new[:, ~fine_mask], sc["grids"]["fine"][:, ~fine_mask]) and np.abs(new - sc["grids"]["fine"]).max() > 0

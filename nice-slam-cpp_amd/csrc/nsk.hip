@@ -57,7 +57,8 @@ __global__ void k_adam(int n, float* __restrict__ p, float* __restrict__ g, floa
 }
 
 struct AdamSeg { float* p; float* g; float* m; float* v; const uint8_t* mask; int n; float step_size, bc2s; int blk_end;
-                 const int* inv_f; const int* inv_b; float* fimg; float* bimg; };   // decoders: image position of each parameter (-1 none)
+                 const int* inv_f; const int* inv_b; float* fimg; float* bimg;      // decoders: image position of each parameter (-1 none)
+                 const int* inv16; unsigned short* img16; float* img16_tail; int tail_off; };   // bf16 3-piece image (nsk_bf16.h), its fp32 tail
 struct AdamArgs { AdamSeg s[8]; int n; float b1, b2, eps; };
 // all parameter groups of one optimiser step in one launch (3 grid levels + trainable decoders)
 __global__ void k_adam_multi(AdamArgs A)
@@ -86,6 +87,21 @@ __global__ void k_adam_multi(AdamArgs A)
             const int fi = S.inv_f[4 * i + k], bi = S.inv_b[4 * i + k];
             if (fi >= 0) S.fimg[fi] = pp[k];
             if (bi >= 0) S.bimg[bi] = pp[k];
+            if (S.inv16) {
+                const int t = S.inv16[4 * i + k];
+                if (t >= 0) {            // same split as k_pack_bf16
+                    const float x = pp[k];
+                    const __bf16 h = (__bf16)x;
+                    const float r1 = x - (float)h;
+                    const __bf16 m = (__bf16)r1;
+                    const __bf16 l = (__bf16)(r1 - (float)m);
+                    const size_t base = ((size_t)(t >> 9) * 3 * 64 + ((t >> 3) & 63)) * 8 + (t & 7);
+                    S.img16[base] = __builtin_bit_cast(unsigned short, h);
+                    S.img16[base + 64 * 8] = __builtin_bit_cast(unsigned short, m);
+                    S.img16[base + 128 * 8] = __builtin_bit_cast(unsigned short, l);
+                }
+                if (fi >= S.tail_off) S.img16_tail[fi - S.tail_off] = pp[k];
+            }
         }
     }
 }
@@ -376,6 +392,7 @@ struct DecState {
     float* fimg = nullptr; float* bimg = nullptr;
     int* fidx = nullptr; int* bidx = nullptr;
     int* finv = nullptr; int* binv = nullptr;     // inverse of fidx / bidx: image position of each canonical parameter
+    int* inv16 = nullptr;                         // inverse of fidx16
     float* fimg16 = nullptr; int* fidx16 = nullptr; int frag16_n = 0, fimg16_f = 0, tail_off = 0, tail16_off = 0;   // bf16 3-piece forward image
     int fimg_n = 0, bimg_n = 0;
     int trainable = 0;
@@ -405,7 +422,7 @@ struct nsk_ctx {
     void* fr_tmp = nullptr; size_t fr_cap = 0;      // nsk_frustum_mask scratch
     int adam_step[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
-    int matmul_mode = 0;                    // 0 fp32 MFMA, 1 bf16 3-piece split (forward)
+    int matmul_mode = 1;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split (fp32-accurate, nsk_bf16.h)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
     // optional per-kernel timing with HIP events on the context's stream (nsk_profile_begin / _end)
     bool prof = false;
@@ -505,7 +522,7 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
     for (int i = 0; i < 4; ++i) {
         hipFree(c->grid[i].v); hipFree(c->grid[i].m); hipFree(c->grid[i].s); hipFree(c->grid[i].mask);
         hipFree(c->dec[i].p); hipFree(c->dec[i].m); hipFree(c->dec[i].s); hipFree(c->dec[i].fimg); hipFree(c->dec[i].bimg);
-        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv);
+        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv); hipFree(c->dec[i].inv16);
         hipFree(c->dec[i].fimg16); hipFree(c->dec[i].fidx16);
     }
     hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal); hipFree(c->fr_tmp);
@@ -754,6 +771,10 @@ extern "C" int nsk_decoder_upload(nsk_ctx* c, int w, const float* h, size_t n)
             HIPCHK(hipMalloc(&D.fimg16, (size_t)D.fimg16_f * 4)); HIPCHK(hipMalloc(&D.fidx16, i16.size() * 4));
             HIPCHK(hipMemset(D.fimg16, 0, (size_t)D.fimg16_f * 4));
             HIPCHK(hipMemcpy(D.fidx16, i16.data(), i16.size() * 4, hipMemcpyHostToDevice));
+            std::vector<int> inv16(n4, -1);
+            for (size_t k = 0; k < i16.size(); ++k) if (i16[k] >= 0) { if (inv16[i16[k]] != -1) return fail("decoder %d: parameter %d appears twice in the bf16 image", w, i16[k]); inv16[i16[k]] = (int)k; }
+            HIPCHK(hipMalloc(&D.inv16, n4 * 4));
+            HIPCHK(hipMemcpy(D.inv16, inv16.data(), n4 * 4, hipMemcpyHostToDevice));
         }
         {
             std::vector<int> finv(n4, -1), binv(n4, -1);
@@ -1253,6 +1274,21 @@ static void invert4(const float* m, float* inv)          // Gauss-Jordan with pa
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) inv[4 * i + j] = (float)a[i][4 + j];
 }
 
+#ifdef NSK_EXPERIMENT
+extern "C" int nsk_dbg_set(nsk_ctx* c, int flags)
+{
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nsk_dbg_flags), &flags, sizeof(int)));
+    return 0;
+}
+extern "C" int nsk_dbg_read_ts(nsk_ctx* c, unsigned long long* out)      // [2][1024][4]
+{
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_dbg_ts), sizeof(unsigned long long) * 2 * 1024 * 4));
+    return 0;
+}
+#endif
+
 extern "C" int nsk_frustum_mask(nsk_ctx* c, int level, const float* d_depth, int H, int W, float fx, float fy, float cx, float cy,
                                 const float h_c2w[16], uint8_t* h_mask_out)
 {
@@ -1378,12 +1414,12 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
             adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, S.step_size, S.bc2s);
             S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.mask = nullptr; S.n = n4;
             S.inv_f = D.finv; S.inv_b = D.binv; S.fimg = D.fimg; S.bimg = D.bimg;
+            if (D.fimg16) { S.inv16 = D.inv16; S.img16 = reinterpret_cast<unsigned short*>(D.fimg16); S.img16_tail = D.fimg16 + D.tail16_off; S.tail_off = D.tail_off; }
             blocks += (n4 / 4 + 255) / 256; S.blk_end = blocks;
         }
         c->touched[NSK_GROUP_DECODERS] = false;
     }
     if (AA.n) { ProfScope ps(c, "adam_multi"); k_adam_multi<<<blocks, 256, 0, c->stream>>>(AA); }
-    if (c->matmul_mode == 1) for (int w = 1; w < 4; ++w) if (c->dec[w].trainable && c->dec[w].loaded && AA.n) { ProfScope ps(c, "pack_bf16"); CHK(repack16(c, w)); }
     if (PA.n) { ProfScope ps(c, "pack_images"); k_pack_multi<<<pblocks, 256, 0, c->stream>>>(PA); }
     HIPCHK(hipGetLastError());
     return 0;

@@ -168,7 +168,7 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
     const f4* src = reinterpret_cast<const f4*>(A.img16);
     for (int i = threadIdx.x; i < I::TOTAL_F / 4; i += 64 * NW) smem[i] = src[i];
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const bf8* img = reinterpret_cast<const bf8*>(smem);
     const float* imgf = reinterpret_cast<const float*>(smem);
     const int ntasks = (A.M + 15) >> 4;

@@ -22,6 +22,9 @@ struct GridD {              // one feature grid level, voxel-major [Z][Y][X][32]
 };
 
 #define NSK_INF __builtin_huge_valf()
+#ifdef NSK_EXPERIMENT
+__device__ int nsk_dbg_flags;
+#endif
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -73,6 +76,7 @@ __device__ __forceinline__ float wave_sum(float v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }   // every lane active
 __device__ __forceinline__ float wave_max(float v)
 {
 #pragma unroll
@@ -462,7 +466,7 @@ __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int n
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     for (int i = threadIdx.x; i < A.img_f4; i += 64 * NW) smem[i] = A.img[i];
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const float* imgf = reinterpret_cast<const float*>(smem);
     const int ntasks = (A.M + 15) >> 4;
     for (int task = bid * NW + wave; task < ntasks; task += nb * NW) {
@@ -531,8 +535,20 @@ __device__ __forceinline__ void block_sum(const float* __restrict__ x, int n, fl
     if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += sh[w]; *out = s; }
 }
 // (a 1024-thread form, 4 waves per SIMD at 128 VGPRs, measured 126 us against 73 us for this one at 1000 rays)
+#ifdef NSK_EXPERIMENT
+// per-workgroup (start, end, role, xcc) stamps of the last fwd [0] / bwd [1] multi launch (tools/exp_ts.py)
+__device__ unsigned long long nsk_dbg_ts[2][1024][4];
+#define NSK_TS_BEGIN(K) unsigned long long ts0_ = wall_clock64()
+#define NSK_TS_END(K, role) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 1024) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+    nsk_dbg_ts[K][blockIdx.x][0] = ts0_; nsk_dbg_ts[K][blockIdx.x][1] = wall_clock64(); nsk_dbg_ts[K][blockIdx.x][2] = (role); nsk_dbg_ts[K][blockIdx.x][3] = xcc & 15; } } while (0)
+#else
+#define NSK_TS_BEGIN(K)
+#define NSK_TS_END(K, role)
+#endif
+
 __global__ __launch_bounds__(512) void k_decode_fwd_multi(MultiArgs MA)
 {
+    NSK_TS_BEGIN(0);
     int r = 0;
     while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
     const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];
@@ -543,6 +559,7 @@ __global__ __launch_bounds__(512) void k_decode_fwd_multi(MultiArgs MA)
     case 2: decode_fwd_body<2, 8>(MA.a[r], bid, nb); break;
     default: decode_fwd_body<3, 8>(MA.a[r], bid, nb); break;
     }
+    NSK_TS_END(0, r);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -684,12 +701,66 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// scatter-add of a 16-sample tile's feature gradient into the grid gradient (voxel-major).  The tile is
-// transposed through per-wave LDS scratch so that each atomic wave-instruction adds two full 128-byte voxel
-// lines (the full-rate shape of global_atomic_add_f32, MI355X guide "Global float atomics").
-// scratch: gct[16][36] floats + vox[16][8] ints + wts[16][8] floats  (3328 bytes)
+// scatter-add of a 16-sample tile's feature gradient into the grid gradient (voxel-major).  The tile's g_c is
+// transposed through per-wave LDS scratch so that each atomic wave-instruction adds two full 128-byte voxel lines
+// (the full-rate shape of global_atomic_add_f32, MI355X guide "Global float atomics"): lanes 0-31 own corners
+// 0-3 (dz = 0), lanes 32-63 corners 4-7 (dz = 1), of channel lane & 31.
+// Samples of a tile are consecutive along a ray (sorted by depth), so runs of samples share a cell: their
+// contributions are summed in registers and flushed once at the end of the run.  Cell ids come from the owning
+// lanes (v_readlane with a constant lane: lane jj holds sample jj's Tri), so run starts and ends are scalar flags
+// known without an LDS round trip, the accumulation is straight-line code, and the only branches are the uniform
+// ones around the flushes (measured: the branchy per-sample loop it replaces cost more than the atomics).
+// The optimiser mask is not consulted: Adam skips masked voxels and clears their gradient (k_adam_multi).
+// scratch: gct[16][36] floats + wts[16][8] floats  (2816 bytes)
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const f4 (&gc)[2], int lane, bool valid,
+                                             float* __restrict__ scratch)
+{
+    const int j = lane & 15, g = lane >> 4;
+    float* gct = scratch;                                   // [16][36]
+    float* wt = scratch + 16 * 36;                          // [16][8]
+    *reinterpret_cast<f4*>(gct + j * 36 + 4 * g) = valid ? gc[0] : (f4)(0.f);
+    *reinterpret_cast<f4*>(gct + j * 36 + 16 + 4 * g) = valid ? gc[1] : (f4)(0.f);
+    if (g == 0) {     // static indices only (a per-lane pick of two corners would index the register array dynamically)
+        *reinterpret_cast<f4*>(wt + j * 8) = valid ? (f4){T.w[0], T.w[1], T.w[2], T.w[3]} : (f4)(0.f);
+        *reinterpret_cast<f4*>(wt + j * 8 + 4) = valid ? (f4){T.w[4], T.w[5], T.w[6], T.w[7]} : (f4)(0.f);
+    }
+    int cell[17];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) cell[jj] = __builtin_amdgcn_readlane(T.vox[0], jj);
+    cell[16] = -1;
+    lds_fence();
+    const int ch = lane & 31;
+    const bool hf = lane >= 32;
+    float* const gch = G.g + ch;
+#ifdef NSK_EXPERIMENT
+    const bool dbg_noatomic = nsk_dbg_flags & 1;            // tools/exp_ts.py: keep the loop, drop the atomics
+#endif
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const float v = gct[jj * 36 + ch];
+        const f4 w4 = *reinterpret_cast<const f4*>(wt + jj * 8 + (hf ? 4 : 0));
+        const float keep = (jj > 0 && cell[jj] == cell[jj - 1]) ? 1.f : 0.f;        // scalar
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(w4[c], v, acc[c] * keep);
+        if (cell[jj] != cell[jj + 1]) {                                             // uniform: the run ends here
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int lo = __builtin_amdgcn_readlane(T.vox[c], jj), hi = __builtin_amdgcn_readlane(T.vox[4 + c], jj);
+                const int vox = hf ? hi : lo;
+#ifdef NSK_EXPERIMENT
+                if (dbg_noatomic) { if (acc[c] == 12345.678f) gch[0] = 1.f; continue; }
+#endif
+                atomicAdd(gch + (size_t)vox * 32, acc[c]);
+            }
+        }
+    }
+    lds_fence();
+}
+
+// per-sample serial form (LDS-resident indices, few registers): used where register pressure matters more than latency
+__device__ __forceinline__ void scatter_tile_serial(const GridD& G, const Tri& T, const f4 (&gc)[2], int lane, bool valid,
                                              float* __restrict__ scratch)
 {
     const int j = lane & 15, g = lane >> 4;
@@ -778,7 +849,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     constexpr bool NEED_E = XYZ && RAYS;
     constexpr int IMG_F = XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL;
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     float* scratch = smf + IMG_F + wave * 960;                  // per-wave scatter scratch (3840 B)
     for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.bimg[i];

@@ -172,7 +172,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     constexpr int FWD_F = XYZ ? FI::TOTAL : CoarseFwdImg::TOTAL;
     constexpr int IMG_F = FWD_LDS ? FWD_F : 0;
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     float* pn = smf + IMG_F;                        // shared panel
     float* scratch = pn + PN_FLOATS + wave * 832;   // per-wave scatter scratch
@@ -243,13 +243,13 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             f4 go;
 #pragma unroll
             for (int i = 0; i < 4; ++i) go[i] = (4 * g + i) < OD ? gout[(4 * g + i) < OD ? (4 * g + i) : 0] : 0.f;
-            pn_put(pn, 0, wave, lane, go);
+            if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, go);
             const f4* h4 = XYZ ? C.h[4] : CC.h[4];
-            pn_put(pn, PN_GROWS, wave, lane, h4[0]);
-            pn_put(pn, PN_GROWS + 16, wave, lane, h4[1]);
+            if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, h4[0]);
+            if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16, wave, lane, h4[1]);
             NSK_BAR();
             constexpr TrainPhase P = plan.p[PL::P_OUT];
-            pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+            if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
             NSK_BAR();
         }
         f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
@@ -261,13 +261,13 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             if constexpr (XYZ) {
                 gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);                 // g_c += fc[l]^T g_h
                 // ---- phase FC_l: G = g_h, X = c ------------------------------------------------------------
-                pn_put(pn, 0, wave, lane, gh[0]);
-                pn_put(pn, 16, wave, lane, gh[1]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, gh[0]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, 16, wave, lane, gh[1]);
 #pragma unroll
-                for (int q = 0; q < CQ; ++q) pn_put(pn, PN_GROWS + 16 * q, wave, lane, C.xc[q]);
+                for (int q = 0; q < CQ; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16 * q, wave, lane, C.xc[q]);
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_FC0 + l];
-                pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
                 NSK_BAR();
             }
             f4 ga[2];
@@ -277,15 +277,15 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
             // ---- phase W_l: G = g_a, X = layer input ----------------------------------------------------------
             {
-                pn_put(pn, 0, wave, lane, ga[0]);
-                pn_put(pn, 16, wave, lane, ga[1]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, ga[0]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, 16, wave, lane, ga[1]);
                 if constexpr (XYZ) {
                     if constexpr (l == 0 || l == 3) {
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) pn_put(pn, PN_GROWS + 16 * q, wave, lane, C.xe[q]);
+                        for (int q = 0; q < 6; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16 * q, wave, lane, C.xe[q]);
                     } else {
-                        pn_put(pn, PN_GROWS, wave, lane, C.h[l - 1][0]);
-                        pn_put(pn, PN_GROWS + 16, wave, lane, C.h[l - 1][1]);
+                        if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, C.h[l - 1][0]);
+                        if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16, wave, lane, C.h[l - 1][1]);
                     }
                 } else {
                     if constexpr (l == 0 || l == 3) { pn_put(pn, PN_GROWS, wave, lane, CC.xc[0]); pn_put(pn, PN_GROWS + 16, wave, lane, CC.xc[1]); }
@@ -293,15 +293,15 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 }
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_W0 + l];
-                pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
                 NSK_BAR();
                 if constexpr (l == 3) {        // second input panel of layer 3: h2 (G panel unchanged)
                     const f4* h2 = XYZ ? C.h[2] : CC.h[2];
-                    pn_put(pn, PN_GROWS, wave, lane, h2[0]);
-                    pn_put(pn, PN_GROWS + 16, wave, lane, h2[1]);
+                    if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, h2[0]);
+                    if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16, wave, lane, h2[1]);
                     NSK_BAR();
                     constexpr TrainPhase P2 = plan.p[PL::P_W3H];
-                    pn_tiles<P2.nslots>(pn, P2.RT, P2.NC, P2.rowsum, wave, lane, acc + P2.slot0);
+                    if (!NSK_DBG(A, 13)) pn_tiles<P2.nslots>(pn, P2.RT, P2.NC, P2.rowsum, wave, lane, acc + P2.slot0);
                     NSK_BAR();
                 }
             }
@@ -341,12 +341,12 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 f4 pq;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
-                pn_put(pn, 0, wave, lane, pq);
+                if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, pq);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) pn_put(pn, PN_GROWS + 16 * q, wave, lane, ge[q]);
+                for (int q = 0; q < 6; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16 * q, wave, lane, ge[q]);
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_DB];
-                pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
                 NSK_BAR();
             }
             if constexpr (RAYS) {
@@ -372,9 +372,8 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 }
             }
         }
-        if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) scatter_tile(A.grid, T, gc, lane, valid, scratch);
+        if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) scatter_tile_serial(A.grid, T, gc, lane, valid, scratch);
     }
-    if (NSK_DBG(A, 11)) return;
     // ---- single flush of this wave's output tiles -------------------------------------------------------------
     float* slab = A.g_dec + (size_t)bid * ((plan_total<WHICH>() + 3) & ~3);
     pn_flush<plan.p[PL::P_OUT].nslots>(slab, plan.p[PL::P_OUT], wave, lane, acc + plan.p[PL::P_OUT].slot0);
@@ -393,6 +392,7 @@ template <bool RAYS>
 __global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
 {
     if (MA.sum_n > 0 && blockIdx.x == gridDim.x - 1) { block_sum(MA.sum_src, MA.sum_n, MA.sum_dst); return; }
+    NSK_TS_BEGIN(1);
     int r = 0;
     while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
     const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];
@@ -408,4 +408,5 @@ __global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
     case 6: decode_bwd_body<3, RAYS>(MA.a[r], bid, nb); break;
     default: decode_bwd_train_body<3, RAYS>(MA.a[r], bid, nb); break;
     }
+    NSK_TS_END(1, r);
 }

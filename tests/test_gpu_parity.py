@@ -220,11 +220,14 @@ def test_reference_sized_scene_forward(oracle32):
     assert wn.min() >= 0 and wn.sum(1).max() <= 1 + 1e-5
 
 
-def test_mapping_steps_match_oracle(oracle32):
-    """north_star metric: optimised grids (and colour decoder) after Adam steps, 1e-4 relative L2"""
+@pytest.mark.parametrize("matmul_mode", [1, 0])
+def test_mapping_steps_match_oracle(matmul_mode, oracle32):
+    """north_star metric: optimised grids (and colour decoder) after Adam steps, 1e-4 relative L2; both forward
+    matrix paths (1 = bf16 3-piece split, the default, whose fragment image the fused Adam kernel refreshes; 0 = fp32 MFMA)"""
     sc = _scene(21, grid_std=0.05)
     rays = scenes.make_rays(22, 200, sc["bound"], n_frames=2)
     ctx = make_ctx(sc, trainable=["color"])
+    ctx.set_matmul_mode(matmul_mode)
     rng = np.random.default_rng(5)
     masks = {k: rng.random(sc["grids"][k].shape[1:]) < 0.7 for k in ("middle", "fine", "color")}
     for k, m in masks.items():

@@ -120,12 +120,11 @@ def main():
     flags = pkg.nsk.GRAD_GRIDS | pkg.nsk.GRAD_DECODERS
 
     with torch.cuda.stream(ctx.tstream):
-        slab = ctx.grad_slab()
-
         def step(i):
             ro, rd, gd, gc, gmax = batches[i % len(batches)]
             ctx.map_step(args.stage, ro, rd, gd, gc, gmax, w_color, True, flags=flags, loss=loss)
-            nd.allreduce_grads(slab)                             # the one exchange of the path (no-op at N=1)
+            if world > 1:                                        # the one exchange of the path; grad_slab() completes the
+                nd.allreduce_grads(ctx.grad_slab())              # step's pending gradient reductions before it is read
             ctx.adam_step(lr)
 
         for i in range(args.warmup):

@@ -193,7 +193,10 @@ int nsk_zero_grads(nsk_ctx* ctx);
 
 /* ---- multi-GPU ------------------------------------------------------------------------------------------- */
 /* The gradient slab (all grid gradients, all decoder gradients, one loss scalar) is one contiguous device
- * buffer so that a mapping step needs exactly one all-reduce. */
+ * buffer so that a mapping step needs exactly one all-reduce.  The decoder gradients of a step
+ * are summed into the slab lazily (inside nsk_adam_step when nobody looks earlier): nsk_grad_slab, nsk_allreduce_grads and
+ * nsk_decoder_grad_download complete that sum first, so call nsk_grad_slab after nsk_map_step, every step, before reading
+ * or exchanging the slab yourself. */
 int nsk_grad_slab(nsk_ctx* ctx, float** d_ptr, size_t* n_floats);
 /* ncclAllReduce(sum, fp32) of the slab on the context's stream; comm is an ncclComm_t (RCCL). */
 int nsk_allreduce_grads(nsk_ctx* ctx, void* nccl_comm);

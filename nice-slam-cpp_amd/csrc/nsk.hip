@@ -58,7 +58,8 @@ __global__ void k_adam(int n, float* __restrict__ p, float* __restrict__ g, floa
 
 struct AdamSeg { float* p; float* g; float* m; float* v; const uint8_t* mask; int n; float step_size, bc2s; int blk_end;
                  const int* inv_f; const int* inv_b; float* fimg; float* bimg;      // decoders: image position of each parameter (-1 none)
-                 const int* inv16; unsigned short* img16; float* img16_tail; int tail_off; };   // bf16 3-piece image (nsk_bf16.h), its fp32 tail
+                 const int* inv16; unsigned short* img16; float* img16_tail; int tail_off;
+                 const float* slabs; int nslabs, slab_stride; };                      // pending per-workgroup gradient slabs (k_decode_bwd_multi)   // bf16 3-piece image (nsk_bf16.h), its fp32 tail
 struct AdamArgs { AdamSeg s[8]; int n; float b1, b2, eps; };
 // all parameter groups of one optimiser step in one launch (3 grid levels + trainable decoders)
 __global__ void k_adam_multi(AdamArgs A)
@@ -67,11 +68,25 @@ __global__ void k_adam_multi(AdamArgs A)
     while (r < A.n - 1 && (int)blockIdx.x >= A.s[r].blk_end) ++r;
     const AdamSeg& S = A.s[r];
     const int b0 = r == 0 ? 0 : A.s[r - 1].blk_end;
-    const int i = (blockIdx.x - b0) * blockDim.x + threadIdx.x;
+    int i = (blockIdx.x - b0) * blockDim.x + threadIdx.x;
+    f4 extra = (f4)(0.f);
+    if (S.slabs) {      // decoder whose gradient still sits in per-workgroup slabs: 32 float4 per block, 8 threads sum 1/8 of the slabs each
+        __shared__ f4 red[8][32];
+        const int pi = threadIdx.x & 31, sg = threadIdx.x >> 5;
+        i = (blockIdx.x - b0) * 32 + pi;
+        f4 part = (f4)(0.f);
+        if (4 * i < S.n)
+            for (int sl = sg; sl < S.nslabs; sl += 8) part += *reinterpret_cast<const f4*>(S.slabs + (size_t)sl * S.slab_stride + 4 * i);
+        red[sg][pi] = part;
+        __syncthreads();
+        if (sg != 0) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) extra += red[k][pi];
+    }
     if (4 * i >= S.n) return;
     f4* g4 = reinterpret_cast<f4*>(S.g) + i;
     if (S.mask && !S.mask[i >> 3]) { *g4 = (f4)(0.f); return; }
-    f4 gg = *g4, pp = reinterpret_cast<f4*>(S.p)[i], mm = reinterpret_cast<f4*>(S.m)[i], vv = reinterpret_cast<f4*>(S.v)[i];
+    f4 gg = *g4 + extra, pp = reinterpret_cast<f4*>(S.p)[i], mm = reinterpret_cast<f4*>(S.m)[i], vv = reinterpret_cast<f4*>(S.v)[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         mm[k] = A.b1 * mm[k] + (1.f - A.b1) * gg[k];
@@ -422,6 +437,7 @@ struct nsk_ctx {
     void* fr_tmp = nullptr; size_t fr_cap = 0;      // nsk_frustum_mask scratch
     int adam_step[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
+    int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
     int matmul_mode = 1;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split (fp32-accurate, nsk_bf16.h)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
     // optional per-kernel timing with HIP events on the context's stream (nsk_profile_begin / _end)
@@ -743,6 +759,8 @@ static int repack(nsk_ctx* c, int w)
     return 0;
 }
 
+static int flush_pending(nsk_ctx* c);
+
 extern "C" size_t nsk_decoder_param_count(int which) { return which_ok(which) ? (size_t)nsk_dec_layout(which).total : 0; }
 
 extern "C" int nsk_decoder_upload(nsk_ctx* c, int w, const float* h, size_t n)
@@ -812,6 +830,7 @@ extern "C" int nsk_decoder_download(nsk_ctx* c, int w, float* h, size_t n)
 extern "C" int nsk_decoder_grad_download(nsk_ctx* c, int w, float* h, size_t n)
 {
     if (!c || !h || !which_ok(w)) return fail("nsk_decoder_grad_download: bad argument");
+    CHK(flush_pending(c));
     return dec_fetch(c, w, c->slab + c->dec[w].g_off, h, n);
 }
 extern "C" int nsk_decoder_set_trainable(nsk_ctx* c, int w, int t)
@@ -1086,12 +1105,25 @@ extern "C" int nsk_eval_points(nsk_ctx* c, int stage, int M, const float* pts, f
 }
 
 // decoders' backward after k_composite wrote g_raw: ONE launch for every decoder of the stage that needs it
+// sum the per-workgroup decoder-gradient slabs of the last backward into the gradient slab (normally done inside k_adam_multi)
+static int flush_pending(nsk_ctx* c)
+{
+    if (c->pend_w < 0) return 0;
+    const int w = c->pend_w, np = c->dec[w].n, n4 = (np + 3) & ~3;
+    ProfScope ps(c, "dec_grad_reduce");
+    k_dec_grad_reduce<<<dim3((np + 255) / 256, 8), 256, 0, c->stream>>>(np, n4, c->pend_nb, c->ws.dec_slabs, c->slab + c->dec[w].g_off);
+    HIPCHK(hipGetLastError());
+    c->pend_w = -1;
+    return 0;
+}
+
 static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, unsigned flags, float* g_ro, float* g_rd,
                          float* d_loss = nullptr)
 {
     const bool rays = (flags & NSK_GRAD_RAYS) != 0;
     const bool grids = (flags & NSK_GRAD_GRIDS) != 0;
     const int M = N * S;
+    CHK(flush_pending(c));                      // gradients accumulate across calls: the slabs are about to be overwritten
     MultiArgs MA;
     memset(&MA, 0, sizeof(MA));
     int n = 0, cost[3], train_role = -1; size_t lds = 0;
@@ -1140,9 +1172,8 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         int w = MA.which[train_role];
         int nb = MA.wg_end[train_role] - (train_role == 0 ? 0 : MA.wg_end[train_role - 1]);
         int np = c->dec[w].n, n4 = (np + 3) & ~3;
-        ProfScope ps2(c, "dec_grad_reduce");
-        k_dec_grad_reduce<<<dim3((np + 255) / 256, 8), 256, 0, c->stream>>>(np, n4, nb, c->ws.dec_slabs, c->slab + c->dec[w].g_off);
-        HIPCHK(hipGetLastError());
+        (void)np; (void)n4;
+        c->pend_w = w; c->pend_nb = nb;          // summed by k_adam_multi, or by flush_pending when someone reads the slab first
     }
     return 0;
 }
@@ -1414,6 +1445,10 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
             adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, S.step_size, S.bc2s);
             S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.mask = nullptr; S.n = n4;
             S.inv_f = D.finv; S.inv_b = D.binv; S.fimg = D.fimg; S.bimg = D.bimg;
+            if (c->pend_w == w) {
+                S.slabs = c->ws.dec_slabs; S.nslabs = c->pend_nb; S.slab_stride = n4; c->pend_w = -1;
+                blocks += (n4 / 4 + 31) / 32 - (n4 / 4 + 255) / 256;       // 32 float4 per block (see k_adam_multi)
+            }
             if (D.fimg16) { S.inv16 = D.inv16; S.img16 = reinterpret_cast<unsigned short*>(D.fimg16); S.img16_tail = D.fimg16 + D.tail16_off; S.tail_off = D.tail_off; }
             blocks += (n4 / 4 + 255) / 256; S.blk_end = blocks;
         }
@@ -1439,6 +1474,7 @@ extern "C" int nsk_adam_reset(nsk_ctx* c)
 extern "C" int nsk_zero_grads(nsk_ctx* c)
 {
     if (!c) return fail("null ctx");
+    c->pend_w = -1;
     if (c->slab) HIPCHK(hipMemsetAsync(c->slab, 0, c->slab_n * 4, c->stream));
     for (int g = 0; g < NSK_NUM_GROUPS; ++g) c->touched[g] = false;
     return 0;
@@ -1448,6 +1484,7 @@ extern "C" int nsk_zero_grads(nsk_ctx* c)
 extern "C" int nsk_grad_slab(nsk_ctx* c, float** p, size_t* n)
 {
     if (!c || !p || !n) return fail("nsk_grad_slab: null argument");
+    CHK(flush_pending(c));
     *p = c->slab; *n = c->slab_n;
     return 0;
 }
@@ -1455,6 +1492,7 @@ extern "C" int nsk_grad_slab(nsk_ctx* c, float** p, size_t* n)
 extern "C" int nsk_allreduce_grads(nsk_ctx* c, void* comm)
 {
     if (!c || !comm) return fail("nsk_allreduce_grads: null argument");
+    CHK(flush_pending(c));
     typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
     static allreduce_t fn = nullptr;
     if (!fn) {

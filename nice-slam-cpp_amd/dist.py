@@ -24,6 +24,11 @@ def global_depth_max(gt_depth, group=None):
     return float(m)
 
 
+def _world(group=None):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
 def allreduce_grads(slab, group=None):
     """the one exchange of the path: sum the gradient slab (grids + decoders + loss scalar) over ranks, in place"""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -45,8 +50,8 @@ class ShardedMapper:
         if gt_depth_max is None:
             gt_depth_max = global_depth_max(gt_depth, self.group)
         self.backend.map_step(stage, rays_o, rays_d, gt_depth, gt_color, gt_depth_max, w_color, use_color, flags=flags, loss=loss)
-        if self._slab is None:
-            self._slab = self.backend.grad_slab()
-        allreduce_grads(self._slab, self.group)
+        if _world(self.group) > 1:
+            # grad_slab() also completes the step's pending gradient reductions: call it every step, before the exchange
+            allreduce_grads(self.backend.grad_slab(), self.group)
         self.backend.adam_step(lr)
         return gt_depth_max

@@ -1312,6 +1312,12 @@ extern "C" int nsk_dbg_set(nsk_ctx* c, int flags)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nsk_dbg_flags), &flags, sizeof(int)));
     return 0;
 }
+extern "C" int nsk_dbg_read_ph(nsk_ctx* c, unsigned long long* out)      // [8][8][32]
+{
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_dbg_ph), sizeof(unsigned long long) * 8 * 8 * 32));
+    return 0;
+}
 extern "C" int nsk_dbg_read_ts(nsk_ctx* c, unsigned long long* out)      // [2][1024][4]
 {
     HIPCHK(hipStreamSynchronize(c->stream));

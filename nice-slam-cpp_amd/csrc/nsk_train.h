@@ -154,6 +154,12 @@ __device__ __forceinline__ void pn_flush(float* __restrict__ g_dec, const TrainP
 }
 
 #ifdef NSK_EXPERIMENT
+__device__ unsigned long long nsk_dbg_ph[8][8][32];      // [workgroup < 8][wave][point]: s_memtime at points of the LAST iteration
+#define NSK_PH(k) do { if (bid < 8 && lane == 0) nsk_dbg_ph[bid][wave][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NSK_PH(k)
+#endif
+#ifdef NSK_EXPERIMENT
 #define NSK_BAR() do { if (!NSK_DBG(A, 12)) __syncthreads(); } while (0)
 #else
 #define NSK_BAR() __syncthreads()
@@ -170,6 +176,8 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     typedef TrainPlan<WHICH> PL;
     constexpr PL plan{};
     constexpr int FWD_F = XYZ ? FI::TOTAL : CoarseFwdImg::TOTAL;
+    constexpr int BWD_F = XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL;
+    static_assert(BWD_F <= FWD_F, "the backward image shares the forward image's LDS region");
     constexpr int IMG_F = FWD_LDS ? FWD_F : 0;
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -180,9 +188,14 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     __syncthreads();
     const f4* fimg = FWD_LDS ? smem : A.img;
     const float* fimgf = reinterpret_cast<const float*>(fimg);
-    const f4* bimg = A.bimg;                        // backward fragments stream from L2
+    // Where the forward image sits in LDS, the backward (transposed) image takes its place after the forward recompute of
+    // every iteration: streaming the chain's A fragments from L2 instead left every gemm of the chain latency-bound
+    // (measured with in-kernel stamps: 112k of a 154k-cycle iteration in the five layer blocks).
+    const f4* bimg = FWD_LDS ? smem : A.bimg;
     const float* Bm = nullptr;
     if constexpr (XYZ) Bm = fimgf + FI::P_BM;
+    const float* Bmb = nullptr;                     // embedding matrix as seen by the chain (backward image when swapped)
+    if constexpr (XYZ) Bmb = FWD_LDS ? smf + MlpBwdImg::P_BM : Bm;
     const float* Wo = XYZ ? fimgf + FI::P_WO : fimgf + CoarseFwdImg::P_WO;
 
     f4 acc[plan.nslots];
@@ -192,8 +205,15 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     const int ntasks = (A.M + 15) >> 4;
     const int per_iter = nb * 8;
     const int iters = (ntasks + per_iter - 1) / per_iter;
+    const bool scat = (A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9);
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
+        NSK_PH(0);
+        if (FWD_LDS && it > 0) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.img[i];
+            __syncthreads();
+        }
         const int task = (it * nb + bid) * 8 + wave;
         const int m = task * 16 + j;
         const bool valid = m < A.M;
@@ -228,6 +248,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             coarse_forward(fimg, lane, CC);
             mask = CC.mask;
         }
+        NSK_PH(1);
         f4 gh[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -238,6 +259,11 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 for (int o = 0; o < OD; ++o) s += Wo[32 * o + 16 * r + 4 * g + i] * gout[o];
                 gh[r][i] = s;
             }
+        if constexpr (FWD_LDS) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < BWD_F / 4; i += 512) smem[i] = A.bimg[i];
+            __syncthreads();
+        }
         // ---- phase OUT: G = g_out (rows >= OD zero), X = h4 ------------------------------------------------
         {
             f4 go;
@@ -252,6 +278,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
             NSK_BAR();
         }
+        NSK_PH(2);
         f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
         f4 ge[6];
 #pragma unroll
@@ -270,6 +297,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
                 NSK_BAR();
             }
+            if constexpr (l == 3) NSK_PH(13);
             f4 ga[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -295,6 +323,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 constexpr TrainPhase P = plan.p[PL::P_W0 + l];
                 if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
                 NSK_BAR();
+                if constexpr (l == 3) NSK_PH(14);
                 if constexpr (l == 3) {        // second input panel of layer 3: h2 (G panel unchanged)
                     const f4* h2 = XYZ ? C.h[2] : CC.h[2];
                     if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, h2[0]);
@@ -305,8 +334,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                     NSK_BAR();
                 }
             }
+            if constexpr (l == 3) NSK_PH(15);
             if constexpr (XYZ) {
                 if constexpr (l == 3) gemm_e(bimg, MlpBwdImg::W3ET, lane, ga, ge);
+                if constexpr (l == 3) NSK_PH(16);
                 if constexpr (l == 0) gemm_e(bimg, MlpBwdImg::W0ET, lane, ga, ge);
                 if constexpr (l >= 1) {
                     f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
@@ -325,15 +356,21 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             }
         };
         layer(std::integral_constant<int, 4>{});
+        NSK_PH(3);
         layer(std::integral_constant<int, 3>{});
+        NSK_PH(4);
         layer(std::integral_constant<int, 2>{});
+        NSK_PH(5);
         layer(std::integral_constant<int, 1>{});
+        NSK_PH(6);
         layer(std::integral_constant<int, 0>{});
+        NSK_PH(7);
+        NSK_PH(8);
         float gp[3] = {0.f, 0.f, 0.f};
         asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));     // opaque: forces the recomputation below instead of keeping T / cos live
         tri_setup(A.grid, A.bound, px, py, pz, T);
         if constexpr (XYZ) {
-            { f4 e2[6]; embed<true>(Bm, g, px, py, pz, e2, xcos); }
+            { f4 e2[6]; embed<true>(Bmb, g, px, py, pz, e2, xcos); }
 #pragma unroll
             for (int q = 0; q < 6; ++q) ge[q] *= xcos[q];
             // ---- phase DB: G = p (3 rows), X = g_s ----------------------------------------------------------
@@ -352,9 +389,9 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             if constexpr (RAYS) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
-                    f4 b0 = *reinterpret_cast<const f4*>(Bm + 16 * q + 4 * g);
-                    f4 b1 = *reinterpret_cast<const f4*>(Bm + 96 + 16 * q + 4 * g);
-                    f4 b2 = *reinterpret_cast<const f4*>(Bm + 192 + 16 * q + 4 * g);
+                    f4 b0 = *reinterpret_cast<const f4*>(Bmb + 16 * q + 4 * g);
+                    f4 b1 = *reinterpret_cast<const f4*>(Bmb + 96 + 16 * q + 4 * g);
+                    f4 b2 = *reinterpret_cast<const f4*>(Bmb + 192 + 16 * q + 4 * g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { gp[0] += ge[q][i] * b0[i]; gp[1] += ge[q][i] * b1[i]; gp[2] += ge[q][i] * b2[i]; }
                 }
@@ -372,8 +409,11 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 }
             }
         }
-        if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) scatter_tile_serial(A.grid, T, gc, lane, valid, scratch);
+        NSK_PH(9);
+        if (scat) scatter_tile_faces(A.grid, T, gc, lane, valid, scratch);
+        NSK_PH(10);
     }
+    NSK_PH(11);
     // ---- single flush of this wave's output tiles -------------------------------------------------------------
     float* slab = A.g_dec + (size_t)bid * ((plan_total<WHICH>() + 3) & ~3);
     pn_flush<plan.p[PL::P_OUT].nslots>(slab, plan.p[PL::P_OUT], wave, lane, acc + plan.p[PL::P_OUT].slot0);
@@ -381,6 +421,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     NSK_FLUSH(1) NSK_FLUSH(2) NSK_FLUSH(3) NSK_FLUSH(4) NSK_FLUSH(5) NSK_FLUSH(6) NSK_FLUSH(7) NSK_FLUSH(8) NSK_FLUSH(9)
     NSK_FLUSH(10) NSK_FLUSH(11) NSK_FLUSH(12)
 #undef NSK_FLUSH
+    NSK_PH(12);
 }
 
 template <int WHICH, bool RAYS>

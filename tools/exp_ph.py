@@ -1,0 +1,31 @@
+"""experiment: s_memtime stamps inside the trainable-decoder backward (libnsk_exp.so): cycles between points of the last iteration"""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["NSK_LIB"] = os.path.join(ROOT, "nice-slam-cpp_amd", "csrc", "libnsk_exp.so")
+import numpy as np, torch
+import nice_slam_cpp_amd as pkg, scenes
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+sc = scenes.make_scene(42)
+r = scenes.make_rays(1234, N, sc["bound"], n_frames=5)
+ctx = pkg.Context(0); ctx.set_render_opts(); ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"]); ctx.decoder_set_trainable("color", True)
+cu = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+ro, rd, gd, gc = cu(r["rays_o"]), cu(r["rays_d"]), cu(r["gt_depth"]), cu(r["gt_color"])
+loss = torch.zeros(1, device="cuda")
+lib = C.CDLL(os.environ["NSK_LIB"])
+for i in range(5):
+    ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.5, True, flags=3, loss=loss); ctx.zero_grads()
+ctx.sync()
+ph = np.zeros((8, 8, 32), np.uint64)
+lib.nsk_dbg_read_ph(ctx.h, ph.ctypes.data_as(C.c_void_p))
+ph = ph.astype(np.int64)
+names_unused = ["top", "fwd done", "OUT done", "L4", "sc0", "L3", "L2", "L1", "L0", "sc4 done", "DB/rays done", "staged", "tail flush", "slab flush"]
+pts = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
+for b in (0, 3):
+    for w in (0, 5):
+        t = ph[b, w]
+        print("wg", b, "wave", w, " ".join("%s:%d" % (k, t[k] - t[0]) for k in pts))
+d = np.diff(ph[:, :, :13], axis=2)
+t = np.median(ph.reshape(-1, 32), axis=0)
+print("layer 3: FT+FC phase %d, W3(e) phase %d, W3H phase %d, gemm_e %d, rest %d" % (t[13] - t[3], t[14] - t[13], t[15] - t[14], t[16] - t[15], t[4] - t[16]))
+print("median deltas (cycles):", np.median(d.reshape(-1, 12), axis=0).astype(int))

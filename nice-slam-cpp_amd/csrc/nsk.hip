@@ -481,7 +481,7 @@ static size_t bwd_lds_bytes(int w, bool train)
     size_t scratch = 8 * 3840;
     if (!train) return bwd_img_floats(w) * 4 + scratch;
     size_t img = w == 2 ? 0 : fwd_img_floats(w);
-    return (img + PN_FLOATS + 8 * 832) * 4;
+    return (img + PN_FLOATS(w == 2 ? 4 : 2)) * 4;            // the per-wave scatter scratch lives in panel rows 0..63
 }
 
 extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
@@ -1312,10 +1312,10 @@ extern "C" int nsk_dbg_set(nsk_ctx* c, int flags)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nsk_dbg_flags), &flags, sizeof(int)));
     return 0;
 }
-extern "C" int nsk_dbg_read_ph(nsk_ctx* c, unsigned long long* out)      // [8][8][32]
+extern "C" int nsk_dbg_read_ph(nsk_ctx* c, unsigned long long* out)      // [8][8][96]
 {
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_dbg_ph), sizeof(unsigned long long) * 8 * 8 * 32));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_dbg_ph), sizeof(unsigned long long) * 8 * 8 * 96));
     return 0;
 }
 extern "C" int nsk_dbg_read_ts(nsk_ctx* c, unsigned long long* out)      // [2][1024][4]

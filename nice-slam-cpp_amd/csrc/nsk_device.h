@@ -785,10 +785,14 @@ __device__ __forceinline__ void scatter_tile_faces(const GridD& G, const Tri& T,
     int cur[4] = {0, 0, 0, 0};
     int pc = -1, p1 = -1, p2 = -1, p4 = -1;                 // scalars: open cell and its +x / +y / +z neighbour voxels
     auto flush = [&](int c) { atomicAdd(gch + (size_t)cur[c] * 32, acc[c]); };
+    float vv[16]; f4 ww[16];                                // every LDS read up front: none inside the branchy part
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) { vv[jj] = gct[jj * 36 + ch]; ww[jj] = *reinterpret_cast<const f4*>(wt + jj * 8 + (hf ? 4 : 0)); }
+    lds_fence();
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
-        const float v = gct[jj * 36 + ch];
-        const f4 w4 = *reinterpret_cast<const f4*>(wt + jj * 8 + (hf ? 4 : 0));
+        const float v = vv[jj];
+        const f4 w4 = ww[jj];
         const int nc = __builtin_amdgcn_readlane(T.vox[0], jj);
         if (nc != pc) {                                     // uniform
             const int n1 = __builtin_amdgcn_readlane(T.vox[1], jj), n2 = __builtin_amdgcn_readlane(T.vox[2], jj),

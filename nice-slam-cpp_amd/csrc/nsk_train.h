@@ -12,9 +12,10 @@
 #include <type_traits>
 
 #define PN_LD 132                     // panel row stride in floats (128 samples + 4 pad)
-#define PN_GROWS 32                   // rows 0..31: G, rows 32..127: X
-#define PN_ROWS 128
-#define PN_FLOATS (PN_ROWS * PN_LD)   // 16896 floats = 67584 B
+#define PN_GROWS 32                   // rows 0..31: G, rows 32..63: a 32-row X (c, h), rows 64..159: a 96-row X (e, g_s)
+// e is written to rows PN_EROWS(CQ).. once per iteration, in the forward recompute, and read by W3 and W0 (behind the 16*CQ rows of c)
+#define PN_EROWS(CQ) (PN_GROWS + 16 * (CQ))
+#define PN_FLOATS(CQ) ((PN_EROWS(CQ) + 96) * PN_LD)   // CQ = 2: 160 rows = 84480 B; rows 0..63 double as the per-wave scatter scratch
 
 // one phase = one (G, X) pair: RT row tiles of G, NC 16-row chunks of X, optional row sums (bias gradients)
 struct TrainPhase {
@@ -96,7 +97,7 @@ __device__ __forceinline__ void pn_put(float* __restrict__ pn, int row0, int wav
 
 // the tiles of one phase owned by this wave, accumulated over the panel's 128 samples
 template <int NSL>
-__device__ __forceinline__ void pn_tiles(const float* __restrict__ pn, int RT, int NC, int rowsum, int wave, int lane, f4* acc)
+__device__ __forceinline__ void pn_tiles(const float* __restrict__ pn, int RT, int NC, int rowsum, int wave, int lane, f4* acc, int xrow0 = PN_GROWS)
 {
     const int r = lane & 15, sq = lane >> 4;
     const int ntiles = RT * NC + (rowsum ? RT : 0);
@@ -108,7 +109,7 @@ __device__ __forceinline__ void pn_tiles(const float* __restrict__ pn, int RT, i
             const int rt = rs ? tile - RT * NC : tile / NC;
             const int ch = rs ? 0 : tile % NC;
             const float* ga = pn + (16 * rt + r) * PN_LD + 4 * sq;
-            const float* xb = pn + (PN_GROWS + 16 * ch + r) * PN_LD + 4 * sq;
+            const float* xb = pn + (xrow0 + 16 * ch + r) * PN_LD + 4 * sq;
             f4 d0 = acc[k], d1 = (f4)(0.f);
 #pragma unroll
             for (int b = 0; b < 8; b += 2) {
@@ -154,15 +155,20 @@ __device__ __forceinline__ void pn_flush(float* __restrict__ g_dec, const TrainP
 }
 
 #ifdef NSK_EXPERIMENT
-__device__ unsigned long long nsk_dbg_ph[8][8][32];      // [workgroup < 8][wave][point]: s_memtime at points of the LAST iteration
+__device__ unsigned long long nsk_dbg_ph[8][8][96];      // [workgroup < 8][wave][point]: s_memtime at points of the LAST iteration
 #define NSK_PH(k) do { if (bid < 8 && lane == 0) nsk_dbg_ph[bid][wave][k] = __builtin_readcyclecounter(); } while (0)
+#define NSK_PHI(k) do { if (bid < 8 && lane == 0 && it < 2) nsk_dbg_ph[bid][wave][32 + 32 * it + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define NSK_PH(k)
+#define NSK_PHI(k)
 #endif
+// workgroup barrier for LDS data only: __syncthreads() also drains vmcnt, i.e. every outstanding global load, store and
+// atomic of the wave (an atomic stays counted for thousands of cycles), although nothing in global memory is exchanged here
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef NSK_EXPERIMENT
-#define NSK_BAR() do { if (!NSK_DBG(A, 12)) __syncthreads(); } while (0)
+#define NSK_BAR() do { if (!NSK_DBG(A, 12)) lds_barrier(); } while (0)
 #else
-#define NSK_BAR() __syncthreads()
+#define NSK_BAR() lds_barrier()
 #endif
 
 template <int WHICH, bool RAYS>
@@ -183,7 +189,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     float* pn = smf + IMG_F;                        // shared panel
-    float* scratch = pn + PN_FLOATS + wave * 832;   // per-wave scatter scratch
+    float* scratch = pn + wave * 832;               // per-wave scatter scratch: panel rows 0..63, idle between the last phase and phase OUT
     for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.img[i];
     __syncthreads();
     const f4* fimg = FWD_LDS ? smem : A.img;
@@ -206,25 +212,39 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     const int per_iter = nb * 8;
     const int iters = (ntasks + per_iter - 1) / per_iter;
     const bool scat = (A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9);
+    // Everything iteration it+1 reads from global memory (its samples, upstream gradient, gathered features, and the
+    // forward image) is fetched at the end of iteration it BEFORE that iteration's scatter: vmcnt retires in order, so a
+    // load issued after the atomics would wait for all of them (measured: 13k cycles at the top of an iteration).
+    struct Staged { float px, py, pz, zz; int n; bool valid; f4 gr; f4 xc[CQ]; } nx;
+    auto stage_a = [&](int it_, Staged& S_) {          // issue the sample loads (no use, no wait)
+        const int task = (it_ * nb + bid) * 8 + wave;
+        const int m = task * 16 + j;
+        S_.valid = m < A.M;
+        const int mm = min(m, A.M - 1);
+        sample_point(A, mm, S_.px, S_.py, S_.pz, S_.zz, S_.n);
+        S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+    };
+    auto stage_b = [&](Staged& S_) {                    // dependent loads: the trilinear gather
+        Tri T_;
+        tri_setup(A.grid, A.bound, S_.px, S_.py, S_.pz, T_);
+        tri_gather(A.grid, T_, g, S_.xc[0], S_.xc[1]);
+        if constexpr (WHICH == 2) {
+            Tri Tm;
+            tri_setup(A.grid_mid, A.bound, S_.px, S_.py, S_.pz, Tm);
+            tri_gather(A.grid_mid, Tm, g, S_.xc[CQ - 2], S_.xc[CQ - 1]);
+        }
+    };
+    if (iters > 0) { stage_a(0, nx); stage_b(nx); }
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
-        NSK_PH(0);
-        if (FWD_LDS && it > 0) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.img[i];
-            __syncthreads();
-        }
-        const int task = (it * nb + bid) * 8 + wave;
-        const int m = task * 16 + j;
-        const bool valid = m < A.M;
-        const int mm = min(m, A.M - 1);
-        float px, py, pz, zz; int n;
-        sample_point(A, mm, px, py, pz, zz, n);
+        NSK_PH(0); NSK_PHI(0);
+        if (FWD_LDS && it > 0) lds_barrier();        // forward image reloaded at the end of the previous iteration
+        const bool valid = nx.valid;
+        float px = nx.px, py = nx.py, pz = nx.pz, zz = nx.zz; const int n = nx.n;
         Tri T;
-        tri_setup(A.grid, A.bound, px, py, pz, T);
         float gout[OD];
         {
-            f4 gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+            f4 gr = nx.gr;
             if (!valid) gr = (f4)(0.f);
             if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
             else gout[0] = gr[3];
@@ -234,21 +254,19 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         f4 xcos[6];
         unsigned long long mask;
         if constexpr (XYZ) {
-            tri_gather(A.grid, T, g, C.xc[0], C.xc[1]);
-            if constexpr (WHICH == 2) {
-                Tri Tm;
-                tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
-                tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
-            }
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) C.xc[q] = nx.xc[q];
             embed<false>(Bm, g, px, py, pz, C.xe, xcos);     // cos is recomputed after the chain (24 fewer live registers)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) pn_put(pn, PN_EROWS(CQ) + 16 * q, wave, lane, C.xe[q]);     // X of phases W3 and W0; xe is dead after the forward
             mlp_forward<CQ>(fimg, lane, C);
             mask = C.mask;
         } else {
-            tri_gather(A.grid, T, g, CC.xc[0], CC.xc[1]);
+            CC.xc[0] = nx.xc[0]; CC.xc[1] = nx.xc[1];
             coarse_forward(fimg, lane, CC);
             mask = CC.mask;
         }
-        NSK_PH(1);
+        NSK_PH(1); NSK_PHI(1);
         f4 gh[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -260,9 +278,9 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 gh[r][i] = s;
             }
         if constexpr (FWD_LDS) {
-            __syncthreads();
+            lds_barrier();
             for (int i = threadIdx.x; i < BWD_F / 4; i += 512) smem[i] = A.bimg[i];
-            __syncthreads();
+            lds_barrier();
         }
         // ---- phase OUT: G = g_out (rows >= OD zero), X = h4 ------------------------------------------------
         {
@@ -278,7 +296,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
             NSK_BAR();
         }
-        NSK_PH(2);
+        NSK_PH(2); NSK_PHI(2);
         f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
         f4 ge[6];
 #pragma unroll
@@ -297,7 +315,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
                 NSK_BAR();
             }
-            if constexpr (l == 3) NSK_PH(13);
+            if constexpr (l == 3) NSK_PH(13); NSK_PHI(13);
             f4 ga[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -309,8 +327,6 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 if (!NSK_DBG(A, 14)) pn_put(pn, 16, wave, lane, ga[1]);
                 if constexpr (XYZ) {
                     if constexpr (l == 0 || l == 3) {
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16 * q, wave, lane, C.xe[q]);
                     } else {
                         if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, C.h[l - 1][0]);
                         if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16, wave, lane, C.h[l - 1][1]);
@@ -321,9 +337,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 }
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_W0 + l];
-                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                constexpr int xrow0 = (XYZ && (l == 0 || l == 3)) ? PN_EROWS(CQ) : PN_GROWS;
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, xrow0);
                 NSK_BAR();
-                if constexpr (l == 3) NSK_PH(14);
+                if constexpr (l == 3) NSK_PH(14); NSK_PHI(14);
                 if constexpr (l == 3) {        // second input panel of layer 3: h2 (G panel unchanged)
                     const f4* h2 = XYZ ? C.h[2] : CC.h[2];
                     if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, h2[0]);
@@ -334,10 +351,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                     NSK_BAR();
                 }
             }
-            if constexpr (l == 3) NSK_PH(15);
+            if constexpr (l == 3) NSK_PH(15); NSK_PHI(15);
             if constexpr (XYZ) {
                 if constexpr (l == 3) gemm_e(bimg, MlpBwdImg::W3ET, lane, ga, ge);
-                if constexpr (l == 3) NSK_PH(16);
+                if constexpr (l == 3) NSK_PH(16); NSK_PHI(16);
                 if constexpr (l == 0) gemm_e(bimg, MlpBwdImg::W0ET, lane, ga, ge);
                 if constexpr (l >= 1) {
                     f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
@@ -356,16 +373,17 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             }
         };
         layer(std::integral_constant<int, 4>{});
-        NSK_PH(3);
+        NSK_PH(3); NSK_PHI(3);
         layer(std::integral_constant<int, 3>{});
-        NSK_PH(4);
+        NSK_PH(4); NSK_PHI(4);
         layer(std::integral_constant<int, 2>{});
-        NSK_PH(5);
+        NSK_PH(5); NSK_PHI(5);
         layer(std::integral_constant<int, 1>{});
-        NSK_PH(6);
+        NSK_PH(6); NSK_PHI(6);
         layer(std::integral_constant<int, 0>{});
-        NSK_PH(7);
-        NSK_PH(8);
+        NSK_PH(7); NSK_PHI(7);
+        if (it + 1 < iters) stage_a(it + 1, nx);
+        NSK_PH(8); NSK_PHI(8);
         float gp[3] = {0.f, 0.f, 0.f};
         asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));     // opaque: forces the recomputation below instead of keeping T / cos live
         tri_setup(A.grid, A.bound, px, py, pz, T);
@@ -380,10 +398,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
                 if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, pq);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16 * q, wave, lane, ge[q]);
+                for (int q = 0; q < 6; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PN_EROWS(CQ) + 16 * q, wave, lane, ge[q]);
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_DB];
-                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PN_EROWS(CQ));
                 NSK_BAR();
             }
             if constexpr (RAYS) {
@@ -409,9 +427,17 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 }
             }
         }
-        NSK_PH(9);
+        NSK_PH(9); NSK_PHI(9);
+        if (it + 1 < iters) {
+            stage_b(nx);
+            if constexpr (FWD_LDS) {
+                lds_barrier();                        // every wave is done with the backward image
+                for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.img[i];
+            }
+        }
+        NSK_PH(17); NSK_PHI(17);
         if (scat) scatter_tile_faces(A.grid, T, gc, lane, valid, scratch);
-        NSK_PH(10);
+        NSK_PH(10); NSK_PHI(10);
     }
     NSK_PH(11);
     // ---- single flush of this wave's output tiles -------------------------------------------------------------

@@ -16,7 +16,7 @@ lib = C.CDLL(os.environ["NSK_LIB"])
 for i in range(5):
     ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.5, True, flags=3, loss=loss); ctx.zero_grads()
 ctx.sync()
-ph = np.zeros((8, 8, 32), np.uint64)
+ph = np.zeros((8, 8, 96), np.uint64)
 lib.nsk_dbg_read_ph(ctx.h, ph.ctypes.data_as(C.c_void_p))
 ph = ph.astype(np.int64)
 names_unused = ["top", "fwd done", "OUT done", "L4", "sc0", "L3", "L2", "L1", "L0", "sc4 done", "DB/rays done", "staged", "tail flush", "slab flush"]
@@ -28,4 +28,11 @@ for b in (0, 3):
 d = np.diff(ph[:, :, :13], axis=2)
 t = np.median(ph.reshape(-1, 32), axis=0)
 print("layer 3: FT+FC phase %d, W3(e) phase %d, W3H phase %d, gemm_e %d, rest %d" % (t[13] - t[3], t[14] - t[13], t[15] - t[14], t[16] - t[15], t[4] - t[16]))
+print("stage+reload %d, scatter %d" % (t[17] - t[9], t[10] - t[17]))
 print("median deltas (cycles):", np.median(d.reshape(-1, 12), axis=0).astype(int))
+
+order = [0, 1, 2, 3, 13, 14, 15, 16, 4, 5, 6, 7, 8, 9, 17, 10]
+for itn in (0, 1):
+    tt = np.median(ph[:, :, 32 + 32 * itn: 64 + 32 * itn].reshape(-1, 32), axis=0)
+    t0 = np.median(ph[:, :, 32].reshape(-1))
+    print("iteration", itn, "start at", int(tt[0] - t0), " ".join("%d:%d" % (k, tt[k] - tt[0]) for k in order))

@@ -168,15 +168,16 @@ def main():
     dom_s = prof[dom][1] / prof[dom][0] * 1e-3
     flops = 2.0 * MAC[dom] * M
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    # (profiles/r01b_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the
+    # (profiles/r01c_pmc_hbm.json, tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the
     # MI355X guide prescribes for gfx950).  Only valid for the default 1000-ray workload the passes were run on.
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01b_pmc_hbm.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01c_pmc_hbm.json")
     if os.path.exists(pmc_path) and N == 1000 and args.stage == "color":
         pmc = json.load(open(pmc_path))
-        kname = {"decode_bwd_multi": "void k_decode_bwd_multi<false>(M", "decode_fwd_multi": "k_decode_fwd_multi(MultiArgs)"}.get(dom)
-        if kname and (kname + "|FETCH_SIZE") in pmc:
-            traffic = (2.0 * pmc[kname + "|FETCH_SIZE"] + pmc[kname + "|WRITE_SIZE"]) * 1024.0
+        prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "k_decode_fwd_multi_bf16"}.get(dom)
+        get = lambda c: next((v for k, v in pmc.items() if prefix and k.startswith(prefix) and k.endswith("|" + c)), None)
+        if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
+            traffic = (2.0 * get("FETCH_SIZE") + get("WRITE_SIZE")) * 1024.0
     roof = {"bound": "mfma", "kernel": dom, "achieved": flops / dom_s / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": flops / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
             "avg_launch_us": dom_s * 1e6, "alg_flops_per_launch": flops,
@@ -191,7 +192,8 @@ def main():
         "config": {"workload": "configs[1]: config/nice_slam.yaml grids (bound of src/main.cpp:33, 3-level grid + colour), "
                                "%d rays x 48 samples per GPU, colour-stage mapping iteration "
                                "(forward + L1 depth/colour loss + backward to middle/fine/colour grids and colour decoder + Adam)" % N,
-                   "rays_per_gpu": N, "samples_per_ray": S, "stage": args.stage, "parallelism": "rays sharded x%d, 1 all-reduce/step" % world},
+                   "rays_per_gpu": N, "samples_per_ray": S, "stage": args.stage,
+                   "matmul": "forward: fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs per product (fp32-accurate); backward: fp32 MFMA", "parallelism": "rays sharded x%d, 1 all-reduce/step" % world},
         "roofline": roof,
         "step_rooflines": {"alg_bytes_per_step": step_bytes, "hbm_frac": step_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS,
                            "alg_flops_per_step": step_flops, "fp32_frac": step_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},

@@ -95,6 +95,13 @@ int nsk_set_mask(nsk_ctx* ctx, int level, const uint8_t* h_mask_zyx);
 int nsk_frustum_mask(nsk_ctx* ctx, int level, const float* d_depth, int H, int W, float fx, float fy, float cx, float cy,
                      const float h_c2w[16], uint8_t* h_mask_out);
 
+/* Mapper::keyframe_selection_overlap (src/Mapper.cpp:132-196; include/torchlib/utils.h:58-130): the rays of N pixels of the
+ * current frame (device arrays, e.g. from nsk_rays_from_pixels) are sampled at n_samples depths in [0.8 depth, depth + 0.5] and
+ * projected into each of K keyframes (h_c2w: K row-major 4x4 poses, host); h_percent[k] = fraction of the points inside keyframe
+ * k's image (20-pixel edge, in front of the camera).  Ranking and truncation to the window stay with the caller (Mapper). */
+int nsk_keyframe_overlap(nsk_ctx* ctx, int N, const float* d_rays_o, const float* d_rays_d, const float* d_gt_depth, int n_samples,
+                         int H, int W, float fx, float fy, float cx, float cy, int K, const float* h_c2w, float* h_percent);
+
 /* ---- decoders (src/models/MLP.cpp:3-49,104-138; src/models/GaussianFFT.cpp:3-8) -------------------------- */
 /* packed parameter order (row-major [out,in] as torch::nn::Linear):
  *   middle/fine/color: B[3][93], pts_linear[0..4].{weight,bias}, fc[0..4].{weight,bias}, output_linear.{weight,bias}

@@ -391,6 +391,39 @@ __global__ void k_frustum_pass2(FrustumArgs A, const float* __restrict__ dep, co
     mask[v] = (uint8_t)m;
 }
 
+// Keyframe overlap (next row N3): Mapper::keyframe_selection_overlap, reference src/Mapper.cpp:132-196.  One workgroup per
+// keyframe projects the N x ns sample points of the current frame into that keyframe and counts those inside its image.
+struct OverlapArgs { int N, ns, H, W, K; float fx, fy, cx, cy; };
+__global__ __launch_bounds__(256) void k_keyframe_overlap(OverlapArgs A, const float* __restrict__ ro, const float* __restrict__ rd,
+                                                           const float* __restrict__ gd, const float* __restrict__ w2c_all,
+                                                           float* __restrict__ percent)
+{
+    __shared__ int sh[4];
+    const float* w2c = w2c_all + 16 * blockIdx.x;
+    const int total = A.N * A.ns;
+    int count = 0;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int n = i / A.ns, s = i - n * A.ns;
+        const float nearv = mul_rn(gd[n], 0.8f), farv = add_rn(gd[n], 0.5f);
+        const float t = linspace01(s, A.ns);
+        const float z = add_rn(mul_rn(nearv, sub_rn(1.f, t)), mul_rn(farv, t));
+        float p[3], cam[3];
+        for (int a = 0; a < 3; ++a) p[a] = add_rn(ro[3 * n + a], mul_rn(rd[3 * n + a], z));
+        for (int a = 0; a < 3; ++a)
+            cam[a] = add_rn(add_rn(add_rn(mul_rn(w2c[4 * a], p[0]), mul_rn(w2c[4 * a + 1], p[1])), mul_rn(w2c[4 * a + 2], p[2])), w2c[4 * a + 3]);
+        cam[0] = -cam[0];
+        const float zc = add_rn(cam[2], 1e-5f);
+        const float u = div_rn(add_rn(mul_rn(A.fx, cam[0]), mul_rn(A.cx, cam[2])), zc);
+        const float v = div_rn(add_rn(mul_rn(A.fy, cam[1]), mul_rn(A.cy, cam[2])), zc);
+        if (u < (float)(A.W - 20) && u > 20.f && v < (float)(A.H - 20) && v > 20.f && zc < 0.f) ++count;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) percent[blockIdx.x] = div_rn((float)(sh[0] + sh[1] + sh[2] + sh[3]), (float)total);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------
@@ -1362,6 +1395,33 @@ extern "C" int nsk_frustum_mask(nsk_ctx* c, int level, const float* d_depth, int
         HIPCHK(hipMemcpyAsync(h_mask_out, G.mask, nvox, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+extern "C" int nsk_keyframe_overlap(nsk_ctx* c, int N, const float* d_ro, const float* d_rd, const float* d_gt_depth, int n_samples,
+                                    int H, int W, float fx, float fy, float cx, float cy, int K, const float* h_c2w, float* h_percent)
+{
+    if (!c || !d_ro || !d_rd || !d_gt_depth || !h_c2w || !h_percent) return fail("nsk_keyframe_overlap: null argument");
+    if (N <= 0 || n_samples <= 0 || K < 0) return fail("nsk_keyframe_overlap: bad sizes");
+    if (K == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<float> w2c((size_t)K * 16);
+    for (int k = 0; k < K; ++k) invert4(h_c2w + 16 * k, w2c.data() + 16 * k);
+    const size_t need = (size_t)K * 17 * 4;
+    if (need > c->fr_cap * 9 + 16 || !c->fr_tmp) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->fr_tmp);
+        c->fr_cap = (need + 8) / 9;
+        HIPCHK(hipMalloc(&c->fr_tmp, c->fr_cap * 9 + 16));
+    }
+    float* d_w2c = reinterpret_cast<float*>(c->fr_tmp); float* d_pct = d_w2c + (size_t)K * 16;
+    HIPCHK(hipMemcpyAsync(d_w2c, w2c.data(), (size_t)K * 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));         // w2c is a stack-lifetime host buffer
+    OverlapArgs A; A.N = N; A.ns = n_samples; A.H = H; A.W = W; A.K = K; A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy;
+    k_keyframe_overlap<<<K, 256, 0, c->stream>>>(A, d_ro, d_rd, d_gt_depth, d_w2c, d_pct);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_percent, d_pct, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

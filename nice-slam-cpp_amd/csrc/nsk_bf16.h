@@ -172,12 +172,15 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
     const bf8* img = reinterpret_cast<const bf8*>(smem);
     const float* imgf = reinterpret_cast<const float*>(smem);
     const int ntasks = (A.M + 15) >> 4;
+    // the sample loads (z, ray) of the next tile are issued before this tile's MLP: one of the two dependent L2 round
+    // trips (z -> p -> gather) leaves the critical path (29 % of wave time was s_waitcnt, profiles/README.md)
+    SampleRaw nx;
+    sample_load(A, min((bid * NW + wave) * 16 + j, A.M - 1), nx);
     for (int task = bid * NW + wave; task < ntasks; task += nb * NW) {
         asm volatile("" ::: "memory");
         const int m = task * 16 + j;
-        const int mm = min(m, A.M - 1);
-        float px, py, pz, zz; int n;
-        sample_point(A, mm, px, py, pz, zz, n);
+        float px, py, pz;
+        sample_finish(A, nx, px, py, pz);
         Tri T;
         tri_setup(A.grid, A.bound, px, py, pz, T);
         Act<CQ> C;
@@ -187,6 +190,7 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
             tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
             tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
         }
+        sample_load(A, min((task + nb * NW) * 16 + j, A.M - 1), nx);      // unconditional (clamped): no branch, no wait here
         f4 dummy[6];
         embed<false>(imgf + I::P_BM, g, px, py, pz, C.xe, dummy);
         mlp_forward_bf16<CQ>(img, imgf, lane, C);

@@ -458,6 +458,24 @@ __device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px
     pz = add_rn(A.rays_o[3 * n + 2], mul_rn(A.rays_d[3 * n + 2], zz));
 }
 
+// the same in two steps, for software pipelining: the loads (no arithmetic on their results) and the point
+struct SampleRaw { float z, o[3], d[3]; };
+__device__ __forceinline__ void sample_load(const DecArgs& A, int mm, SampleRaw& R)
+{
+    if (A.pts) { R.o[0] = A.pts[3 * mm]; R.o[1] = A.pts[3 * mm + 1]; R.o[2] = A.pts[3 * mm + 2]; R.z = 0.f; R.d[0] = R.d[1] = R.d[2] = 0.f; return; }
+    const int n = mm / A.S;
+    R.z = A.z[mm];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { R.o[k] = A.rays_o[3 * n + k]; R.d[k] = A.rays_d[3 * n + k]; }
+}
+__device__ __forceinline__ void sample_finish(const DecArgs& A, const SampleRaw& R, float& px, float& py, float& pz)
+{
+    if (A.pts) { px = R.o[0]; py = R.o[1]; pz = R.o[2]; return; }
+    px = add_rn(R.o[0], mul_rn(R.d[0], R.z));           // reference src/Renderer.cpp:121
+    py = add_rn(R.o[1], mul_rn(R.d[1], R.z));
+    pz = add_rn(R.o[2], mul_rn(R.d[2], R.z));
+}
+
 // bid / nb: this workgroup's index and the number of workgroups working on this decoder (a launch may serve
 // several decoders, each with its own slice of the grid: k_decode_fwd_multi)
 template <int WHICH, int NW = 8>

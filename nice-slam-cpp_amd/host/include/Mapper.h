@@ -1,7 +1,7 @@
 // Same surface as the reference's include/Mapper.h:11-44 for the hot path: Mapper(), run(), optimize_map().
 // get_mask_from_c2w (next row N2) runs on the device (nsk_frustum_mask) when mapping.frustum_feature_selection is set, except on
-// levels where the caller installed its own mask with set_frustum_mask.  keyframe_selection_overlap (next row N3) is not built: the window is
-// the most recent keyframes.
+// levels where the caller installed its own mask with set_frustum_mask.  keyframe_selection_overlap (next row N3) is folded into optimize_map too:
+// the per-keyframe overlap fractions come from nsk_keyframe_overlap, the ranking stays on the host.
 #pragma once
 #include <algorithm>
 #include <iostream>
@@ -28,6 +28,8 @@ class Mapper {
     void seed(uint64_t s) { rng_seed = s; }
     float lr_factor;
     float last_loss = 0.f;
+    std::vector<float> last_overlap;       // overlap fraction of keyframes [0, n-1) in that call (empty if not ranked)
+    std::vector<int> last_window;          // keyframe indices of the last optimize_map call (-1 = current frame)
 
   private:
     Renderer renderer;

@@ -537,12 +537,35 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
                           torch::Tensor gt_cur_c2w, torch::Tensor& cur_c2w, NICE& decoders)     // Mapper.cpp:198-491
 {
     (void)gt_cur_c2w;
-    // window: the most recent keyframes (the overlap ranking of :132-196 is next row N3) + the current frame (-1)
+    // window (:200-216): the mapping_window_size-2 keyframes that overlap the current frame most (keyframe_selection_overlap,
+    // :132-196, over all keyframes but the last as in the original's keyframe_dict[:-1]), the last keyframe, the current frame (-1)
     std::vector<int> optimize_frame;
-    int nkf = (int)keyframe_vector.size();
-    for (int k = std::max(0, nkf - (mapping_window_size - 1)); k < nkf; ++k) optimize_frame.push_back(k);
+    const int nkf = (int)keyframe_vector.size();
+    if (nkf > 1 && keyframe_selection_method == "overlap") {
+        torch::Tensor ro, rd, gd, gc;
+        get_samples(0, H, 0, W, 100, H, W, fx, fy, cx, cy, cur_c2w, cur_gt_depth, cur_gt_color, ro, rd, gd, gc);     // :137
+        DevBuf d_ro, d_rd, d_gd;
+        d_ro.upload(ro); d_rd.upload(rd); d_gd.upload(gd);
+        std::vector<float> poses((size_t)(nkf - 1) * 16), pct(nkf - 1);
+        for (int k = 0; k < nkf - 1; ++k) {
+            torch::Tensor m = keyframe_vector[k].est_c2w.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+            std::memcpy(poses.data() + 16 * k, m.data_ptr<float>(), 16 * sizeof(float));
+        }
+        check(nsk_keyframe_overlap(ctx(), (int)ro.size(0), d_ro.p, d_rd.p, d_gd.p, 16, H, W, fx, fy, cx, cy, nkf - 1, poses.data(), pct.data()));
+        std::vector<int> order;
+        for (int k = 0; k < nkf - 1; ++k) if (pct[k] > 0.f) order.push_back(k);                                     // :178-179
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pct[a] > pct[b]; });                  // :186-190
+        const int num = std::max(0, mapping_window_size - 2);
+        if ((int)order.size() > num) order.resize(num);                                                             // :194-195 (size_t underflow read as intended)
+        optimize_frame = order;
+        last_overlap = pct;
+    } else {
+        for (int k = std::max(0, nkf - (mapping_window_size - 1)); k < nkf - 1; ++k) optimize_frame.push_back(k);
+    }
+    if (nkf > 0) optimize_frame.push_back(nkf - 1);                                           // :211
     int oldest_frame = optimize_frame.empty() ? -1 : *std::min_element(optimize_frame.begin(), optimize_frame.end());
     optimize_frame.push_back(-1);                                                             // :216
+    last_window = optimize_frame;
     const int pixs_per_image = mapping_pixels / (int)optimize_frame.size();                   // :223 (D30)
 
     nskh::set_bound_ctx(bound);

@@ -146,6 +146,30 @@ int main(int argc, char** argv)
         for (auto k : {"grid_middle", "grid_fine", "grid_color"}) save_npy(out + "map_" + k + ".npy", c.at(k));
         save_npy(out + "map_dec_color_delta.npy", (decoders.color_decoder->packed() - color_before).abs().max().reshape({1}));
         save_npy(out + "map_dec_fine_delta.npy", (decoders.fine_decoder->packed() - fine_before).abs().max().reshape({1}));
+        // ---- keyframe window by overlap (Mapper.cpp:132-216): five keyframes with very different views of the current frame
+        {
+            std::string ns2 = NS_YAML;
+            ns2.replace(ns2.find("keyframe_every: 50"), 18, "keyframe_every: 1 ");
+            std::istringstream ns2_s(ns2);
+            YAML::Node nsb = YAML::Load(ns2_s);
+            Mapper mapper2(nsb, cf, false);
+            mapper2.set_bound(bound);
+            auto roty = [&](float a) { torch::Tensor m = torch::eye(4); m[0][0] = std::cos(a); m[0][2] = std::sin(a); m[2][0] = -std::sin(a); m[2][2] = std::cos(a); return m; };
+            std::vector<torch::Tensor> poses;
+            for (float a : {0.0f, 3.14159f, 0.65f, 0.78f, 0.25f, 0.0f}) {          // same view, opposite, 37 deg, 45 deg, 14 deg; frame 5 = current
+                torch::Tensor p = torch::matmul(c2w.clone(), roty(a));
+                p.index_put_({Slice(None, 3), 3}, c2w.index({Slice(None, 3), 3}));
+                poses.push_back(p);
+            }
+            c10::Dict<std::string, torch::Tensor> c2;
+            for (auto k : {"grid_coarse", "grid_middle", "grid_fine", "grid_color"}) c2.insert(k, c.at(k).clone());
+            for (int idx = 0; idx < 6; ++idx) mapper2.run(decoders, c2, poses, color_img, depth_img, poses[idx], idx, 100);
+            torch::Tensor win = torch::zeros({(int64_t)mapper2.last_window.size()});
+            for (size_t k = 0; k < mapper2.last_window.size(); ++k) win[k] = (float)mapper2.last_window[k];
+            save_npy(out + "kf_window.npy", win);
+            save_npy(out + "kf_overlap.npy", torch::tensor(mapper2.last_overlap));
+            save_npy(out + "kf_poses.npy", torch::stack(poses));
+        }
         // the renderer must see the optimised grids / decoder without any explicit upload
         renderer.render_batch_ray(c, decoders, rays_d, rays_o, "color", gt_depth, rgb, depth, var, weights);
         save_npy(out + "r3_depth.npy", depth); save_npy(out + "r3_rgb.npy", rgb);

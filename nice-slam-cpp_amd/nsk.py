@@ -17,7 +17,7 @@ GROUP_DECODERS, GROUP_COARSE, GROUP_MIDDLE, GROUP_FINE, GROUP_COLOR, GROUP_CAMER
 # every symbol include/nsk.h declares
 SYMBOLS = (
     "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
-    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask",
+    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap",
     "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
@@ -187,6 +187,18 @@ class Context:
         _chk(lib().nsk_frustum_mask(self.h, _stage(level), _ptr(depth_img), H, W, C.c_float(fx), C.c_float(fy), C.c_float(cx),
                                     C.c_float(cy), m.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
         return out.reshape(Z, Y, X).astype(bool)
+
+    @_ordered
+    def keyframe_overlap(self, rays_o, rays_d, gt_depth, intr, HW, c2w_list, n_samples=16):
+        """Mapper::keyframe_selection_overlap: fraction of the frame's sample points seen by each keyframe -> float32 [K]"""
+        import numpy as np
+        m = np.ascontiguousarray(np.asarray(c2w_list, dtype=np.float32).reshape(-1, 16))
+        out = np.zeros(m.shape[0], np.float32)
+        fx, fy, cx, cy = intr
+        _chk(lib().nsk_keyframe_overlap(self.h, rays_o.shape[0], _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), n_samples, int(HW[0]), int(HW[1]),
+                                        C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), m.shape[0], m.ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def decoder_upload(self, which, packed):
         import numpy as np

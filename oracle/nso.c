@@ -887,3 +887,34 @@ NSO_API int nso_frustum_mask(const real* bound, int Z, int Y, int X, const real*
     free(dep); free(zz); free(inimg);
     return cnt;
 }
+
+/* Mapper::keyframe_selection_overlap, reference src/Mapper.cpp:132-196 (next row N3; also include/torchlib/utils.h:58-130):
+ * the rays of `N` pixels of the current frame are sampled at `ns` depths between 0.8*depth and depth+0.5 and projected into
+ * every keyframe; percent[k] = fraction of those points that fall inside keyframe k's image (20-pixel edge) in front of its
+ * camera.  The caller ranks the keyframes by percent (descending, stable) and keeps the first k_overlap with percent > 0
+ * (the reference's `selected_kf.size()-k_overlap > 0` on size_t is read as size > k_overlap). */
+NSO_API void nso_keyframe_overlap(int N, const real* rays_o, const real* rays_d, const real* gt_depth, int ns, int H, int W,
+                                  real fx, real fy, real cx, real cy, int K, const real* c2w /*[K][16]*/, real* percent /*[K]*/)
+{
+    const int edge = 20;
+    for (int k = 0; k < K; ++k) {
+        real w2c[16];
+        invert_rigid4(c2w + 16 * k, w2c);
+        long count = 0;
+        for (int n = 0; n < N; ++n) {
+            const real nearv = gt_depth[n] * (real)0.8, farv = gt_depth[n] + (real)0.5;
+            for (int s = 0; s < ns; ++s) {
+                const real t = linspace01(s, ns);
+                const real z = nearv * ((real)1 - t) + farv * t;
+                real p[3], cam[3];
+                for (int a = 0; a < 3; ++a) p[a] = rays_o[3 * n + a] + rays_d[3 * n + a] * z;
+                for (int a = 0; a < 3; ++a) cam[a] = w2c[4 * a] * p[0] + w2c[4 * a + 1] * p[1] + w2c[4 * a + 2] * p[2] + w2c[4 * a + 3];
+                cam[0] = -cam[0];
+                const real zc = cam[2] + (real)1e-5;
+                const real u = (fx * cam[0] + cx * cam[2]) / zc, v = (fy * cam[1] + cy * cam[2]) / zc;
+                if (u < (real)(W - edge) && u > (real)edge && v < (real)(H - edge) && v > (real)edge && zc < 0) ++count;
+            }
+        }
+        percent[k] = (real)count / (real)((long)N * ns);
+    }
+}

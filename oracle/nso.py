@@ -258,6 +258,17 @@ class Oracle:
         self.lib.nso_frustum_mask(self._p(b), Z, Y, X, self._p(d), H, W, R(fx), R(fy), R(cx), R(cy), self._p(m), int(is_coarse), self._p(mask))
         return mask.astype(bool)
 
+    def keyframe_overlap(self, rays_o, rays_d, gt_depth, intr, HW, c2w_list, n_samples=16):
+        """Mapper::keyframe_selection_overlap: fraction of the current frame's sample points seen by each keyframe -> [K]"""
+        ro, rd, gd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3)), self.arr(gt_depth)
+        m = self.arr(np.asarray(c2w_list).reshape(-1, 16))
+        out = np.zeros(m.shape[0], self.dt)
+        R = self.creal
+        fx, fy, cx, cy = intr
+        self.lib.nso_keyframe_overlap(ro.shape[0], self._p(ro), self._p(rd), self._p(gd), n_samples, int(HW[0]), int(HW[1]), R(fx), R(fy),
+                                      R(cx), R(cy), m.shape[0], self._p(m), self._p(out))
+        return out
+
     def inside_filter(self, bound, rays_o, rays_d, gt_depth):
         b = self.arr(bound, (6,))
         ro, rd, gd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3)), self.arr(gt_depth)

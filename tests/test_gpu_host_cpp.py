@@ -93,3 +93,24 @@ def test_mapper_optimises_grids_and_colour_decoder(dump, oracle32):
     d2 = dict(decs); d2["color"] = dump["dec_color_after"]
     ref = oracle32.render_forward(oracle32.opts(bound), g2, d2, "color", dump["rays_o"], dump["rays_d"], dump["gt_depth"])
     assert rel_l2(dump["r3_depth"], ref["depth"]) < 1e-4 and rel_l2(dump["r3_rgb"], ref["rgb"]) < 1e-4
+
+
+def test_mapper_window_is_ranked_by_overlap(dump, oracle32):
+    """Mapper::keyframe_selection_overlap (src/Mapper.cpp:132-216) through the C++ Mapper: the window of the sixth frame holds
+    the mapping_window_size-2 = 3 best-overlapping keyframes of [0..3] (fractions from nsk_keyframe_overlap on 100 random
+    pixels, ranked on the host: descending, zero overlap dropped), then the last keyframe (4), then the current frame (-1).
+    The fractions themselves are checked against the oracle on a regular pixel lattice of the same frame (sampling noise
+    allowed); their exact agreement on identical rays is test_gpu_parity.py::test_keyframe_overlap_matches_oracle."""
+    poses, pct = dump["kf_poses"], dump["kf_overlap"]
+    assert pct.shape == (4,)
+    order = [int(k) for k in np.argsort(-pct, kind="stable") if pct[k] > 0][:3]
+    assert [int(x) for x in dump["kf_window"]] == order + [4, -1], (dump["kf_window"], pct)
+    H, W, fx, fy, cx, cy = 48, 64, 40.0, 40.0, 32.0, 24.0
+    jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    cur = poses[5].astype(np.float64)
+    dirs = np.stack([(ii - cx) / fx, -(jj - cy) / fy, -np.ones_like(ii, dtype=np.float64)], -1).reshape(-1, 3)
+    rd = dirs @ cur[:3, :3].T
+    ro = np.broadcast_to(cur[:3, 3], rd.shape)
+    ref = oracle32.keyframe_overlap(ro, rd, dump["map_depth_img"].reshape(-1), (fx, fy, cx, cy), (H, W), poses[:4])
+    assert ref[1] == 0 and pct[1] == 0 and ref[0] > ref[2] > ref[3] > 0        # opposite view never overlaps
+    assert np.abs(pct - ref).max() < 0.08, (pct, ref)

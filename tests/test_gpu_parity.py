@@ -387,3 +387,16 @@ def test_frustum_mask_matches_oracle(oracle32):
     fine_mask = oracle32.frustum_mask(b, sc["grids"]["fine"].shape[1:], depth, (fx, fy, cx, cy), c2w)
     new = ctx.grid_download("fine")
     assert np.array_equal(new[:, ~fine_mask], sc["grids"]["fine"][:, ~fine_mask]) and np.abs(new - sc["grids"]["fine"]).max() > 0
+
+
+def test_keyframe_overlap_matches_oracle(oracle32):
+    """next row N3: Mapper::keyframe_selection_overlap (src/Mapper.cpp:132-196): the per-keyframe fractions are counts over the
+    same fp32 arithmetic, so they must agree exactly; the ranking the Mapper derives from them follows"""
+    from test_oracle import _overlap_case
+    r, cams, intr, HW = _overlap_case(seed=5, n=100, K=9)
+    ref = oracle32.keyframe_overlap(r["rays_o"], r["rays_d"], r["gt_depth"], intr, HW, cams)
+    sc = scenes.make_scene(1, grid_shapes=scenes.SMALL_GRID_SHAPES)
+    ctx = make_ctx(sc)
+    got = ctx.keyframe_overlap(cu(r["rays_o"]), cu(r["rays_d"]), cu(r["gt_depth"]), intr, HW, cams)
+    assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.float32)), (got, ref)
+    assert len(set(np.argsort(-got, kind="stable")[:3])) == 3 and got.max() > 0.5

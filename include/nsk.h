@@ -174,6 +174,12 @@ int nsk_loss_track(nsk_ctx* ctx, int N, const float* d_depth, const float* d_rgb
  * utils.h:32; streams cannot match, so indices are an input).  d_c2w: 12 floats, row-major [3][4].
  * mode bit0: as-written j_t=(i-cy)/fy without sign flip (D11); bit1: truncate intrinsics to int (D10);
  * 0 = intended OpenGL camera dirs=[(i-cx)/fx, -(j-cy)/fy, -1]. */
+/* raySampler's pixel draw (utils.h:19-36: n indices, with replacement, uniform over the window [H0,H1) x [W0,W1)) and its
+ * gather of the ground truth (utils.h:38-43) on the device.  The draw uses a counter-based hash of (seed, ray index) instead of
+ * torch::randint's stream; pix_i = column, pix_j = row.  d_depth [H][W], d_color [H][W][3] (d_color / d_gt_color may be NULL). */
+int nsk_sample_pixels(nsk_ctx* ctx, unsigned long long seed, int n, int H0, int H1, int W0, int W1, int32_t* d_pix_i, int32_t* d_pix_j);
+int nsk_gather_pixels(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, int H, int W, const float* d_depth,
+                      const float* d_color, float* d_gt_depth, float* d_gt_color);
 int nsk_rays_from_pixels(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy,
                          float cx, float cy, const float* d_c2w, int mode, float* d_rays_o, float* d_rays_d);
 /* d loss / d c2w (12 floats, overwritten) from per-ray gradients */

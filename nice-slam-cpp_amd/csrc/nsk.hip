@@ -424,6 +424,27 @@ __global__ __launch_bounds__(256) void k_keyframe_overlap(OverlapArgs A, const f
     if (threadIdx.x == 0) percent[blockIdx.x] = div_rn((float)(sh[0] + sh[1] + sh[2] + sh[3]), (float)total);
 }
 
+// Pixel draw and ground-truth gather of raySampler (next row N1): reference include/torchlib/utils.h:13-43.  torch::randint's
+// stream cannot be reproduced; the draw uses a counter-based hash of (seed, ray index), the same the perturbation of k_sample uses.
+__global__ void k_sample_pixels(unsigned long long seed, int n, int H0, int W0, int Ww, unsigned long long total, int* __restrict__ pi,
+                                int* __restrict__ pj)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const unsigned long long ind = ((unsigned long long)hash_u32(seed, (uint32_t)r, 0x51u) * total) >> 32;
+    pi[r] = W0 + (int)(ind % (unsigned long long)Ww);
+    pj[r] = H0 + (int)(ind / (unsigned long long)Ww);
+}
+__global__ void k_gather_pixels(int n, const int* __restrict__ pi, const int* __restrict__ pj, int W, const float* __restrict__ depth,
+                                const float* __restrict__ color, float* __restrict__ gd, float* __restrict__ gc)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const size_t p = (size_t)pj[r] * W + pi[r];
+    gd[r] = depth[p];
+    if (color && gc) { gc[3 * r] = color[3 * p]; gc[3 * r + 1] = color[3 * p + 1]; gc[3 * r + 2] = color[3 * p + 2]; }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------
@@ -1422,6 +1443,29 @@ extern "C" int nsk_keyframe_overlap(nsk_ctx* c, int N, const float* d_ro, const 
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_percent, d_pct, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int nsk_sample_pixels(nsk_ctx* c, unsigned long long seed, int n, int H0, int H1, int W0, int W1, int32_t* d_pix_i, int32_t* d_pix_j)
+{
+    if (!c || !d_pix_i || !d_pix_j) return fail("nsk_sample_pixels: null argument");
+    if (n < 0 || H1 <= H0 || W1 <= W0) return fail("nsk_sample_pixels: empty window [%d,%d) x [%d,%d)", H0, H1, W0, W1);
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    k_sample_pixels<<<(n + 255) / 256, 256, 0, c->stream>>>(seed, n, H0, W0, W1 - W0, (unsigned long long)(H1 - H0) * (unsigned long long)(W1 - W0), d_pix_i, d_pix_j);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nsk_gather_pixels(nsk_ctx* c, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, int H, int W, const float* d_depth,
+                                 const float* d_color, float* d_gt_depth, float* d_gt_color)
+{
+    if (!c || !d_pix_i || !d_pix_j || !d_depth || !d_gt_depth) return fail("nsk_gather_pixels: null argument");
+    if (n < 0 || H <= 0 || W <= 0) return fail("nsk_gather_pixels: bad sizes");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    k_gather_pixels<<<(n + 255) / 256, 256, 0, c->stream>>>(n, d_pix_i, d_pix_j, W, d_depth, d_color, d_gt_depth, d_gt_color);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

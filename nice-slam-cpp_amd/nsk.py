@@ -17,7 +17,7 @@ GROUP_DECODERS, GROUP_COARSE, GROUP_MIDDLE, GROUP_FINE, GROUP_COLOR, GROUP_CAMER
 # every symbol include/nsk.h declares
 SYMBOLS = (
     "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
-    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap",
+    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap", "nsk_sample_pixels", "nsk_gather_pixels",
     "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
@@ -187,6 +187,26 @@ class Context:
         _chk(lib().nsk_frustum_mask(self.h, _stage(level), _ptr(depth_img), H, W, C.c_float(fx), C.c_float(fy), C.c_float(cx),
                                     C.c_float(cy), m.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
         return out.reshape(Z, Y, X).astype(bool)
+
+    @_ordered
+    def sample_pixels(self, seed, n, H0, H1, W0, W1):
+        """raySampler's pixel draw on the device -> (pix_i cols, pix_j rows) int32 cuda tensors"""
+        import torch
+        pi = torch.empty(n, dtype=torch.int32, device="cuda:%d" % self.device)
+        pj = torch.empty_like(pi)
+        _chk(lib().nsk_sample_pixels(self.h, C.c_ulonglong(seed), n, H0, H1, W0, W1, _ptr(pi), _ptr(pj)))
+        return pi, pj
+
+    @_ordered
+    def gather_pixels(self, pix_i, pix_j, depth_img, color_img=None):
+        import torch
+        n = pix_i.shape[0]
+        H, W = depth_img.shape
+        gd = torch.empty(n, dtype=torch.float32, device=depth_img.device)
+        gc = torch.empty((n, 3), dtype=torch.float32, device=depth_img.device) if color_img is not None else None
+        _chk(lib().nsk_gather_pixels(self.h, n, _ptr(pix_i), _ptr(pix_j), H, W, _ptr(depth_img), _ptr(color_img) if color_img is not None else None,
+                                     _ptr(gd), _ptr(gc) if gc is not None else None))
+        return gd, gc
 
     @_ordered
     def keyframe_overlap(self, rays_o, rays_d, gt_depth, intr, HW, c2w_list, n_samples=16):

@@ -918,3 +918,26 @@ NSO_API void nso_keyframe_overlap(int N, const real* rays_o, const real* rays_d,
         percent[k] = (real)count / (real)((long)N * ns);
     }
 }
+
+/* raySampler's pixel draw and ground-truth gather, reference include/torchlib/utils.h:13-43 (next row N1).  The reference draws
+ * `n` indices with torch::randint over the cropped window [H0,H1) x [W0,W1) (row-major, utils.h:19-36); that stream cannot be
+ * reproduced, so the draw is restated with this library's counter-based hash: ind = floor(u32 * total / 2^32). */
+NSO_API void nso_sample_pixels(uint64_t seed, int n, int H0, int H1, int W0, int W1, int* pix_i /*col*/, int* pix_j /*row*/)
+{
+    const int Ww = W1 - W0;
+    const uint64_t total = (uint64_t)(H1 - H0) * (uint64_t)Ww;
+    for (int r = 0; r < n; ++r) {
+        const uint64_t ind = ((uint64_t)hash_u32(seed, (uint32_t)r, 0x51u) * total) >> 32;
+        pix_i[r] = W0 + (int)(ind % (uint64_t)Ww);
+        pix_j[r] = H0 + (int)(ind / (uint64_t)Ww);
+    }
+}
+NSO_API void nso_gather_pixels(int n, const int* pix_i, const int* pix_j, int W, const real* depth /*[H][W]*/, const real* color /*[H][W][3]*/,
+                               real* gt_depth, real* gt_color)
+{
+    for (int r = 0; r < n; ++r) {
+        const size_t p = (size_t)pix_j[r] * W + pix_i[r];
+        gt_depth[r] = depth[p];
+        for (int k = 0; k < 3; ++k) gt_color[3 * r + k] = color[3 * p + k];
+    }
+}

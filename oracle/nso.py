@@ -258,6 +258,19 @@ class Oracle:
         self.lib.nso_frustum_mask(self._p(b), Z, Y, X, self._p(d), H, W, R(fx), R(fy), R(cx), R(cy), self._p(m), int(is_coarse), self._p(mask))
         return mask.astype(bool)
 
+    def sample_pixels(self, seed, n, H0, H1, W0, W1):
+        """raySampler's pixel draw (utils.h:19-36) with the library's hash -> (pix_i cols, pix_j rows) int32 [n]"""
+        pi, pj = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self.lib.nso_sample_pixels(C.c_uint64(seed), n, H0, H1, W0, W1, self._p(pi), self._p(pj))
+        return pi, pj
+
+    def gather_pixels(self, pix_i, pix_j, depth_img, color_img):
+        d, c = self.arr(depth_img), self.arr(color_img)
+        pi, pj = np.ascontiguousarray(pix_i, np.int32), np.ascontiguousarray(pix_j, np.int32)
+        gd, gc = np.zeros(len(pi), self.dt), np.zeros((len(pi), 3), self.dt)
+        self.lib.nso_gather_pixels(len(pi), self._p(pi), self._p(pj), d.shape[1], self._p(d), self._p(c), self._p(gd), self._p(gc))
+        return gd, gc
+
     def keyframe_overlap(self, rays_o, rays_d, gt_depth, intr, HW, c2w_list, n_samples=16):
         """Mapper::keyframe_selection_overlap: fraction of the current frame's sample points seen by each keyframe -> [K]"""
         ro, rd, gd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3)), self.arr(gt_depth)

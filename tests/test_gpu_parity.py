@@ -400,3 +400,25 @@ def test_keyframe_overlap_matches_oracle(oracle32):
     got = ctx.keyframe_overlap(cu(r["rays_o"]), cu(r["rays_d"]), cu(r["gt_depth"]), intr, HW, cams)
     assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.float32)), (got, ref)
     assert len(set(np.argsort(-got, kind="stable")[:3])) == 3 and got.max() > 0.5
+
+
+def test_sample_and_gather_pixels_match_oracle(oracle32):
+    """next row N1: raySampler's pixel draw + ground-truth gather on the device (utils.h:13-43), index-exact against the oracle's
+    restatement of the same hash; rays from those pixels through nsk_rays_from_pixels as before"""
+    H, W = 96, 128
+    rng = np.random.default_rng(2)
+    depth = rng.uniform(0.5, 4.0, (H, W)).astype(np.float32)
+    color = rng.random((H, W, 3)).astype(np.float32)
+    sc = scenes.make_scene(1, grid_shapes=scenes.SMALL_GRID_SHAPES)
+    ctx = make_ctx(sc)
+    for seed, n, win in ((11, 1000, (0, H, 0, W)), (12, 333, (10, H - 10, 20, W - 20)), (13, 1, (5, 6, 7, 8))):
+        pi, pj = ctx.sample_pixels(seed, n, *win)
+        ri, rj = oracle32.sample_pixels(seed, n, *win)
+        assert np.array_equal(pi.cpu().numpy(), ri) and np.array_equal(pj.cpu().numpy(), rj)
+        gd, gc = ctx.gather_pixels(pi, pj, cu(depth), cu(color))
+        rgd, rgc = oracle32.gather_pixels(ri, rj, depth, color)
+        assert np.array_equal(gd.cpu().numpy(), rgd) and np.array_equal(gc.cpu().numpy(), rgc)
+    c2w = scenes.make_camera(rng, sc["bound"])
+    ro, rd = ctx.rays_from_pixels(pi, pj, (80.0, 80.0, 63.5, 47.5), cu(np.ascontiguousarray(c2w[:3, :4])))
+    rro, rrd = oracle32.rays_from_pixels(ri, rj, 80.0, 80.0, 63.5, 47.5, c2w)
+    assert np.array_equal(ro.cpu().numpy(), rro) and rel_l2(rd.cpu().numpy(), rrd) < 1e-6

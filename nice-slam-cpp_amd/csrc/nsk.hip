@@ -86,7 +86,12 @@ __global__ void k_adam_multi(AdamArgs A)
     if (4 * i >= S.n) return;
     f4* g4 = reinterpret_cast<f4*>(S.g) + i;
     if (S.mask && !S.mask[i >> 3]) { *g4 = (f4)(0.f); return; }
-    f4 gg = *g4 + extra, pp = reinterpret_cast<f4*>(S.p)[i], mm = reinterpret_cast<f4*>(S.m)[i], vv = reinterpret_cast<f4*>(S.v)[i];
+    const f4 g0 = *g4;
+    f4 gg = g0 + extra, mm = reinterpret_cast<f4*>(S.m)[i], vv = reinterpret_cast<f4*>(S.v)[i];
+    // a parameter that never received a gradient (g = m = v = 0) does not move under Adam: skip its five memory operations
+    if (!S.inv_f && gg[0] == 0.f && gg[1] == 0.f && gg[2] == 0.f && gg[3] == 0.f && mm[0] == 0.f && mm[1] == 0.f && mm[2] == 0.f && mm[3] == 0.f &&
+        vv[0] == 0.f && vv[1] == 0.f && vv[2] == 0.f && vv[3] == 0.f) return;
+    f4 pp = reinterpret_cast<f4*>(S.p)[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         mm[k] = A.b1 * mm[k] + (1.f - A.b1) * gg[k];
@@ -95,7 +100,7 @@ __global__ void k_adam_multi(AdamArgs A)
         pp[k] -= S.step_size * (mm[k] / denom);
     }
     reinterpret_cast<f4*>(S.p)[i] = pp; reinterpret_cast<f4*>(S.m)[i] = mm; reinterpret_cast<f4*>(S.v)[i] = vv;
-    *g4 = (f4)(0.f);
+    if (g0[0] != 0.f || g0[1] != 0.f || g0[2] != 0.f || g0[3] != 0.f) *g4 = (f4)(0.f);
     if (S.inv_f) {      // keep the MFMA fragment images of a trainable decoder in step with its parameters
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -570,7 +575,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     SETB(0) SETB(1) SETB(2) SETB(3)
 #undef SETB
     CHK(set_lds(k_median_thr, 16384 * 4));
-    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16, 160 * 1024));
+    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024));
     if (const char* e = getenv("NSK_MATMUL_MODE")) c->matmul_mode = atoi(e); CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
     *out = c;
     return 0;
@@ -1049,7 +1054,7 @@ static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const fl
     if (c->matmul_mode == 1) {
         size_t lds16 = 0;
         for (int r = 0; r < n; ++r) lds16 = std::max(lds16, MA.which[r] == 0 ? fwd_img_floats(0) * 4 : (size_t)c->dec[MA.which[r]].fimg16_f * 4);
-        k_decode_fwd_multi_bf16<<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);
+        k_decode_fwd_multi_bf16<8><<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);       // 12 waves (168 VGPRs) spill: 59 -> 71 us
     } else
     k_decode_fwd_multi<<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
     HIPCHK(hipGetLastError());

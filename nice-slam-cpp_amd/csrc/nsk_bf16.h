@@ -206,16 +206,17 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
     }
 }
 
-__global__ __launch_bounds__(512) void k_decode_fwd_multi_bf16(MultiArgs MA)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_decode_fwd_multi_bf16(MultiArgs MA)
 {
     int r = 0;
     while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
     const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];
     const int bid = blockIdx.x - b0, nb = MA.wg_end[r] - b0;
     switch (MA.which[r]) {
-    case 0: decode_fwd_body<0, 8>(MA.a[r], bid, nb); break;
-    case 1: decode_fwd_bf16_body<1, 8>(MA.a[r], bid, nb); break;
-    case 2: decode_fwd_bf16_body<2, 8>(MA.a[r], bid, nb); break;
-    default: decode_fwd_bf16_body<3, 8>(MA.a[r], bid, nb); break;
+    case 0: decode_fwd_body<0, NW>(MA.a[r], bid, nb); break;
+    case 1: decode_fwd_bf16_body<1, NW>(MA.a[r], bid, nb); break;
+    case 2: decode_fwd_bf16_body<2, NW>(MA.a[r], bid, nb); break;
+    default: decode_fwd_bf16_body<3, NW>(MA.a[r], bid, nb); break;
     }
 }

@@ -1031,6 +1031,37 @@ static void split_wgs(int num_cu, int ntasks, int n, const int* cost, int* wg_en
     }
 }
 
+// Backward with one trainable role: that role advances in whole iterations (8 tasks per workgroup, all its workgroups in
+// lockstep), so its time is ceil(groups / workgroups) iterations -- a step function -- while a frozen role's time falls
+// smoothly with its workgroups.  Pick the trainable role's share by minimising the modelled makespan instead of in
+// proportion to cost (1024 rays: 3 iterations with the proportional 191 workgroups, 2 with 192).
+static void split_wgs_train(int num_cu, int ntasks, int n, const int* cost, int train_role, int* wg_end)
+{
+    const int groups = std::max(1, (ntasks + 7) / 8);
+    long best = -1; int best_wt = 1;
+    int fsum = 0;
+    for (int r = 0; r < n; ++r) if (r != train_role) fsum += cost[r];
+    for (int wt = 1; wt <= num_cu - (n - 1); ++wt) {
+        long t = (long)((groups + wt - 1) / wt) * cost[train_role] * 1;      // one task per wave per iteration
+        const int rest = num_cu - wt;
+        for (int r = 0; r < n; ++r) {
+            if (r == train_role) continue;
+            const int wr = std::max(1, (int)((long)rest * cost[r] / std::max(1, fsum)));
+            t = std::max(t, (long)((ntasks + 8 * wr - 1) / (8 * wr)) * cost[r]);
+        }
+        if (best < 0 || t < best || (t == best && wt <= groups)) { best = t; best_wt = wt; }   // ties: the most workgroups the role can use
+    }
+    best_wt = std::min(best_wt, groups);
+    const int rest = num_cu - best_wt;
+    int used = 0;
+    for (int r = 0; r < n; ++r) {
+        int k = r == train_role ? best_wt : std::max(1, (int)((long)rest * cost[r] / std::max(1, fsum)));
+        k = std::min(k, std::max(1, (ntasks + 7) / 8));
+        used += k;
+        wg_end[r] = used;
+    }
+}
+
 // all decoders of the stage in ONE launch (workgroup roles), or a plain launch when the stage has one decoder
 static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const float* ro, const float* rd, bool save_masks)
 {
@@ -1218,7 +1249,8 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         return 0;
     }
     MA.n = n;
-    split_wgs(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end);
+    if (train_role >= 0 && n > 1) split_wgs_train(c->num_cu, (M + 15) / 16, n, cost, train_role, MA.wg_end);
+    else split_wgs(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end);
     const int extra = d_loss ? 1 : 0;          // one more workgroup sums the per-ray losses written by k_composite
     if (d_loss) { MA.sum_src = c->ws.ray_loss; MA.sum_dst = d_loss; MA.sum_n = N; }
     {

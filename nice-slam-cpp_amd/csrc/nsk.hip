@@ -477,6 +477,9 @@ struct Workspace {
     int capM = 0, capN = 0;
     float* z = nullptr; float* occ[3] = {nullptr, nullptr, nullptr}; float* rgb4 = nullptr;
     unsigned long long* masks[4] = {nullptr, nullptr, nullptr, nullptr};
+    f4* hsave[4] = {nullptr, nullptr, nullptr, nullptr};     // block outputs of trainable decoders saved by the forward (save_h)
+    size_t hcap[4] = {0, 0, 0, 0};                              // capacity in tiles
+    int hsave_M[4] = {0, 0, 0, 0};                              // sample count of the forward that filled hsave (0 = stale)
     float* g_raw = nullptr; float* ray_loss = nullptr;
     float* tmp_rgb = nullptr; float* tmp_depth = nullptr; float* tmp_var = nullptr;
     float* dec_slabs = nullptr;      // per-workgroup partial decoder gradients [num_cu][20920]
@@ -539,7 +542,7 @@ static size_t bwd_lds_bytes(int w, bool train)
 {
     size_t scratch = 8 * 3840;
     if (!train) return bwd_img_floats(w) * 4 + scratch;
-    size_t img = w == 2 ? 0 : fwd_img_floats(w);
+    size_t img = w == 2 ? 0 : bwd_img_floats(w);          // saved-activation form: only the backward image sits in LDS
     return (img + PN_FLOATS(w == 2 ? 4 : 2)) * 4;            // the per-wave scatter scratch lives in panel rows 0..63
 }
 
@@ -585,6 +588,7 @@ static void free_ws(Workspace& w)
 {
     hipFree(w.z); for (int i = 0; i < 3; ++i) hipFree(w.occ[i]); hipFree(w.rgb4);
     for (int i = 0; i < 4; ++i) hipFree(w.masks[i]);
+    for (int i = 0; i < 4; ++i) { hipFree(w.hsave[i]); w.hsave[i] = nullptr; w.hcap[i] = 0; w.hsave_M[i] = 0; }
     hipFree(w.g_raw); hipFree(w.ray_loss); hipFree(w.tmp_rgb); hipFree(w.tmp_depth); hipFree(w.tmp_var); hipFree(w.dec_slabs);
     w = Workspace();
 }
@@ -922,6 +926,21 @@ static int ensure_ws(nsk_ctx* c, int N, int M)
     return 0;
 }
 
+// the forward of a trainable decoder (all but the fine one, see nsk_train.h) also stores its block outputs for the backward
+static bool saves_h(nsk_ctx* c, int w, bool save_masks) { return save_masks && w != 2 && c->dec[w].trainable; }
+static int ensure_hsave(nsk_ctx* c, int w, int M)
+{
+    Workspace& ws = c->ws;
+    const size_t tiles = (size_t)(M + 15) / 16 + 1;
+    if (tiles > ws.hcap[w]) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(ws.hsave[w]);
+        HIPCHK(hipMalloc(&ws.hsave[w], tiles * 10 * 64 * sizeof(f4)));
+        ws.hcap[w] = tiles;
+    }
+    return 0;
+}
+
 static const int STAGE_DEC[4][3] = {{0, -1, -1}, {1, -1, -1}, {1, 2, -1}, {1, 2, 3}};
 
 static GridD grid_dev(nsk_ctx* c, int level, bool with_grad)
@@ -963,6 +982,8 @@ static int launch_decode_fwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     DecArgs A;
     fill_args(c, A, w, M, S, ro, rd, pts);
     A.masks = save_masks ? c->ws.masks[w] : nullptr;
+    if (save_masks) c->ws.hsave_M[w] = 0;
+    if (saves_h(c, w, save_masks)) { CHK(ensure_hsave(c, w, M)); A.hsave = c->ws.hsave[w]; c->ws.hsave_M[w] = M; }
     int ntasks = (M + 15) / 16;
     size_t lds = fwd_img_floats(w) * 4;
     int maxwg = c->num_cu;        // persistent: one workgroup per CU balances the 16-sample tasks over SIMDs
@@ -990,6 +1011,10 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     A.g_rays_o = g_ro; A.g_rays_d = g_rd;
     A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
     A.flags = flags;
+    if (train && w != 2) {
+        if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
+        A.hsave = c->ws.hsave[w];
+    }
     int ntasks = (M + 15) / 16;
     size_t lds = bwd_lds_bytes(w, train);
     int grid = std::max(1, std::min((ntasks + 7) / 8, c->num_cu));
@@ -1076,6 +1101,8 @@ static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const fl
         int w = STAGE_DEC[stage][r];
         fill_args(c, MA.a[r], w, M, S, ro, rd, nullptr);
         MA.a[r].masks = save_masks ? c->ws.masks[w] : nullptr;
+        if (save_masks) c->ws.hsave_M[w] = 0;
+        if (saves_h(c, w, save_masks)) { CHK(ensure_hsave(c, w, M)); MA.a[r].hsave = c->ws.hsave[w]; c->ws.hsave_M[w] = M; }
         MA.which[r] = w; cost[r] = fcost[w];
         lds = std::max(lds, fwd_img_floats(w) * 4);
     }
@@ -1229,11 +1256,15 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         A.g_raw = c->ws.g_raw;
         A.g_rays_o = g_ro; A.g_rays_d = g_rd;
         A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
-        A.flags = flags;
+        A.flags = (flags & 0xffu) | (M >= 96000 ? 256u : 0u);       // bit 8: face-sharing scatter in the frozen roles
+        if (train && w != 2) {
+            if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
+            A.hsave = c->ws.hsave[w];
+        }
         MA.which[n] = w; MA.train[n] = train ? 1 : 0;
         // measured (1000 and 10000 rays, colour stage): ~65 us per 8-task iteration of the trainable role against ~10 us per
         // task of a frozen role; 170 minimised decode_bwd_multi at both sizes (130: 159/1365 us, 170: 140/1155, 200: 193/1213)
-        static const int frozen_cost = getenv("NSK_FROZEN_COST") ? atoi(getenv("NSK_FROZEN_COST")) : 170;
+        static const int frozen_cost = getenv("NSK_FROZEN_COST") ? atoi(getenv("NSK_FROZEN_COST")) : 210;
         cost[n] = train ? 1000 : frozen_cost;
         lds = std::max(lds, bwd_lds_bytes(w, train));
         if (train) train_role = train_role == -1 ? n : -2;     // -2: more than one trainable decoder -> separate launches below

@@ -203,6 +203,7 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
             }
             if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
         }
+        if (A.hsave) save_h(A.hsave, task, lane, C.h);
     }
 }
 

@@ -441,6 +441,7 @@ struct DecArgs {
     int img_f4;               // forward image size in f4
     float* out;               // occupancy [M] (which<3) or rgb4 [M][4] (color)
     unsigned long long* masks;   // [M][4] ReLU bits or nullptr
+    f4* hsave;                // block outputs h0..h4 of a trainable decoder, [tile][5][2][64 lanes] f4 (lane order = D layout), or nullptr
     // backward only
     const float* g_raw;       // [M][4] = (g_rgb[3], g_sigma)
     float* g_rays_o; float* g_rays_d;    // [N][3] accumulated with atomics, or nullptr
@@ -476,6 +477,16 @@ __device__ __forceinline__ void sample_finish(const DecArgs& A, const SampleRaw&
     pz = add_rn(R.o[2], mul_rn(R.d[2], R.z));
 }
 
+// The backward of a TRAINABLE decoder needs the block outputs h0..h4 as the X operands of its weight gradients.  The
+// forward stores them (one coalesced KiB per quad and tile) instead of the backward recomputing the MLP: 640 B per sample
+// of extra traffic against 277 MFMAs + two LDS image swaps per tile.
+__device__ __forceinline__ void save_h(f4* __restrict__ hsave, int task, int lane, const f4 (&h)[5][2])
+{
+    f4* dst = hsave + ((size_t)task * 10) * 64 + lane;
+#pragma unroll
+    for (int l = 0; l < 5; ++l) { dst[(2 * l) * 64] = h[l][0]; dst[(2 * l + 1) * 64] = h[l][1]; }
+}
+
 // bid / nb: this workgroup's index and the number of workgroups working on this decoder (a launch may serve
 // several decoders, each with its own slice of the grid: k_decode_fwd_multi)
 template <int WHICH, int NW = 8>
@@ -505,6 +516,7 @@ __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int n
                 if (g == 0) A.out[m] = out[0];
                 if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
             }
+            if (A.hsave) save_h(A.hsave, task, lane, C.h);
         } else {
             constexpr int CQ = WHICH == 2 ? 4 : 2;
             constexpr int OD = WHICH == 3 ? 4 : 1;
@@ -528,6 +540,7 @@ __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int n
                 }
                 if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
             }
+            if (A.hsave) save_h(A.hsave, task, lane, C.h);
         }
     }
 }
@@ -905,23 +918,37 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     const float* Wo = XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO;
 
     const int ntasks = (A.M + 15) >> 4;
+    // The next tile's loads are issued at the top of this tile and forced to have landed before this tile's scatter: vmcnt
+    // retires in order, so a load issued after the atomics would wait for all of them (the frozen roles spent more time
+    // there than in their MFMA chain).
+    struct Staged { SampleRaw r; f4 gr; unsigned long long mask; } nx;
+    auto stage = [&](int task_, Staged& S_) {
+        const int mm_ = min(min(task_, ntasks - 1) * 16 + j, A.M - 1);
+        sample_load(A, mm_, S_.r);
+        S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm_ * 4);
+        S_.mask = A.masks[(size_t)mm_ * 4 + g];
+    };
+    stage(bid * 8 + wave, nx);
     for (int task = bid * 8 + wave; task < ntasks; task += nb * 8) {
         asm volatile("" ::: "memory");      // keep the LDS fragment reads inside the loop (LICM would hoist + spill them)
         const int m = task * 16 + j;
         const bool valid = m < A.M;
         const int mm = min(m, A.M - 1);
-        float px, py, pz, zz; int n;
-        sample_point(A, mm, px, py, pz, zz, n);
+        float px, py, pz;
+        sample_finish(A, nx.r, px, py, pz);
+        const float zz = A.pts ? 0.f : nx.r.z;
+        const int n = A.pts ? 0 : mm / A.S;
         Tri T;
         tri_setup(A.grid, A.bound, px, py, pz, T);
         float gout[OD];
         {
-            f4 gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+            f4 gr = nx.gr;
             if (!valid) gr = (f4)(0.f);
             if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
             else gout[0] = gr[3];
         }
-        const unsigned long long mask = A.masks[(size_t)mm * 4 + g];
+        const unsigned long long mask = nx.mask;
+        stage(task + nb * 8, nx);
         f4 xcos[6];
         if constexpr (NEED_E) { f4 e[6]; embed<true>(Bm, g, px, py, pz, e, xcos); }
         f4 gh[2];                                                // g_h4 = Wo^T g_out
@@ -967,6 +994,9 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                 }
             }
         }
+        // opaque use: the staged registers must hold their data here, i.e. the loads retire before the first atomic below
+        asm volatile("" : "+v"(nx.r.z), "+v"(nx.r.o[0]), "+v"(nx.r.o[1]), "+v"(nx.r.o[2]), "+v"(nx.r.d[0]), "+v"(nx.r.d[1]), "+v"(nx.r.d[2]),
+                          "+v"(nx.gr), "+v"(nx.mask));
         if constexpr (RAYS) {       // g_p through the embedding (g_e * cos(pB)) B^T and through the trilinear lookup
             float gp[3] = {0.f, 0.f, 0.f};
             if constexpr (NEED_E) {
@@ -991,7 +1021,12 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                 }
             }
         }
-        if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) scatter_tile(A.grid, T, gc, lane, valid, scratch);
+        if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) {
+            // fewer atomics (face sharing) win once the launch is large enough to press on the chip-wide atomic rate; below that the
+            // straight-line form is quicker for the frozen roles (1000 rays: 119 vs 123 us, 10000 rays: 1085 vs 899 us)
+            if (A.flags & 256u) scatter_tile_faces(A.grid, T, gc, lane, valid, scratch);
+            else scatter_tile(A.grid, T, gc, lane, valid, scratch);
+        }
     }
 }
 

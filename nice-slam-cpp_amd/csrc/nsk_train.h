@@ -177,32 +177,30 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     constexpr bool XYZ = WHICH != 0;
     constexpr int CQ = WHICH == 2 ? 4 : 2;
     constexpr int OD = WHICH == 3 ? 4 : 1;
-    constexpr bool FWD_LDS = WHICH != 2;            // fine: image + panel exceed 160 KiB, stream fragments from L2
+    // SAVED: the forward stored this decoder's block outputs h0..h4 (DecArgs::hsave) and its ReLU bits, so nothing of the MLP
+    // is recomputed here and the backward (transposed) image stays in LDS for the whole kernel.  The fine decoder (64 input
+    // features, images too large for LDS beside the panel) keeps the older form: forward recompute, fragments streamed from L2.
+    constexpr bool SAVED = WHICH != 2;
     typedef MlpFwdImg<CQ> FI;
     typedef TrainPlan<WHICH> PL;
     constexpr PL plan{};
-    constexpr int FWD_F = XYZ ? FI::TOTAL : CoarseFwdImg::TOTAL;
     constexpr int BWD_F = XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL;
-    static_assert(BWD_F <= FWD_F, "the backward image shares the forward image's LDS region");
-    constexpr int IMG_F = FWD_LDS ? FWD_F : 0;
+    constexpr int IMG_F = SAVED ? BWD_F : 0;
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     float* pn = smf + IMG_F;                        // shared panel
     float* scratch = pn + wave * 832;               // per-wave scatter scratch: panel rows 0..63, idle between the last phase and phase OUT
-    for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.img[i];
+    for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.bimg[i];
     __syncthreads();
-    const f4* fimg = FWD_LDS ? smem : A.img;
+    const f4* fimg = A.img;                         // !SAVED only: forward fragments from L2
     const float* fimgf = reinterpret_cast<const float*>(fimg);
-    // Where the forward image sits in LDS, the backward (transposed) image takes its place after the forward recompute of
-    // every iteration: streaming the chain's A fragments from L2 instead left every gemm of the chain latency-bound
-    // (measured with in-kernel stamps: 112k of a 154k-cycle iteration in the five layer blocks).
-    const f4* bimg = FWD_LDS ? smem : A.bimg;
-    const float* Bm = nullptr;
-    if constexpr (XYZ) Bm = fimgf + FI::P_BM;
-    const float* Bmb = nullptr;                     // embedding matrix as seen by the chain (backward image when swapped)
-    if constexpr (XYZ) Bmb = FWD_LDS ? smf + MlpBwdImg::P_BM : Bm;
-    const float* Wo = XYZ ? fimgf + FI::P_WO : fimgf + CoarseFwdImg::P_WO;
+    const f4* bimg = SAVED ? smem : A.bimg;
+    const float* bimgf = reinterpret_cast<const float*>(bimg);
+    const float* Bm = nullptr;                      // embedding matrix [3][96]
+    if constexpr (XYZ) Bm = SAVED ? bimgf + MlpBwdImg::P_BM : fimgf + FI::P_BM;
+    const float* Bmb = Bm;
+    const float* Wo = SAVED ? bimgf + (XYZ ? MlpBwdImg::P_WO : CoarseBwdImg::P_WO) : fimgf + FI::P_WO;
 
     f4 acc[plan.nslots];
 #pragma unroll
@@ -215,7 +213,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     // Everything iteration it+1 reads from global memory (its samples, upstream gradient, gathered features, and the
     // forward image) is fetched at the end of iteration it BEFORE that iteration's scatter: vmcnt retires in order, so a
     // load issued after the atomics would wait for all of them (measured: 13k cycles at the top of an iteration).
-    struct Staged { float px, py, pz, zz; int n; bool valid; f4 gr; f4 xc[CQ]; } nx;
+    struct Staged { float px, py, pz, zz; int n; bool valid; f4 gr; f4 xc[CQ]; f4 h4[2]; unsigned long long mask; } nx;
     auto stage_a = [&](int it_, Staged& S_) {          // issue the sample loads (no use, no wait)
         const int task = (it_ * nb + bid) * 8 + wave;
         const int m = task * 16 + j;
@@ -223,6 +221,11 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         const int mm = min(m, A.M - 1);
         sample_point(A, mm, S_.px, S_.py, S_.pz, S_.zz, S_.n);
         S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+        if constexpr (SAVED) {
+            const int tk = min(task, ntasks - 1);
+            S_.mask = A.masks[(size_t)mm * 4 + g];
+            S_.h4[0] = A.hsave[((size_t)tk * 10 + 8) * 64 + lane]; S_.h4[1] = A.hsave[((size_t)tk * 10 + 9) * 64 + lane];
+        }
     };
     auto stage_b = [&](Staged& S_) {                    // dependent loads: the trilinear gather
         Tri T_;
@@ -238,7 +241,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
         NSK_PH(0); NSK_PHI(0);
-        if (FWD_LDS && it > 0) lds_barrier();        // forward image reloaded at the end of the previous iteration
+        if (it > 0) lds_barrier();                   // panel rows 0..63 were the waves' scatter scratch until here
         const bool valid = nx.valid;
         float px = nx.px, py = nx.py, pz = nx.pz, zz = nx.zz; const int n = nx.n;
         Tri T;
@@ -253,18 +256,18 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         ActC CC;
         f4 xcos[6];
         unsigned long long mask;
+        const int htask = min((it * nb + bid) * 8 + wave, ntasks - 1);          // this wave's tile in hsave
         if constexpr (XYZ) {
 #pragma unroll
             for (int q = 0; q < CQ; ++q) C.xc[q] = nx.xc[q];
             embed<false>(Bm, g, px, py, pz, C.xe, xcos);     // cos is recomputed after the chain (24 fewer live registers)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) pn_put(pn, PN_EROWS(CQ) + 16 * q, wave, lane, C.xe[q]);     // X of phases W3 and W0; xe is dead after the forward
-            mlp_forward<CQ>(fimg, lane, C);
-            mask = C.mask;
+            for (int q = 0; q < 6; ++q) pn_put(pn, PN_EROWS(CQ) + 16 * q, wave, lane, C.xe[q]);     // X of phases W3 and W0; xe is dead from here
+            if constexpr (SAVED) { C.h[4][0] = nx.h4[0]; C.h[4][1] = nx.h4[1]; mask = nx.mask; }
+            else { mlp_forward<CQ>(fimg, lane, C); mask = C.mask; }
         } else {
             CC.xc[0] = nx.xc[0]; CC.xc[1] = nx.xc[1];
-            coarse_forward(fimg, lane, CC);
-            mask = CC.mask;
+            CC.h[4][0] = nx.h4[0]; CC.h[4][1] = nx.h4[1]; mask = nx.mask;
         }
         NSK_PH(1); NSK_PHI(1);
         f4 gh[2];
@@ -277,11 +280,6 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 for (int o = 0; o < OD; ++o) s += Wo[32 * o + 16 * r + 4 * g + i] * gout[o];
                 gh[r][i] = s;
             }
-        if constexpr (FWD_LDS) {
-            lds_barrier();
-            for (int i = threadIdx.x; i < BWD_F / 4; i += 512) smem[i] = A.bimg[i];
-            lds_barrier();
-        }
         // ---- phase OUT: G = g_out (rows >= OD zero), X = h4 ------------------------------------------------
         {
             f4 go;
@@ -303,6 +301,11 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
         auto layer = [&](auto LC) {
             constexpr int l = decltype(LC)::value;
+            if constexpr (SAVED && l >= 1) {          // h[l-1] is the X operand of this layer's weight phase: fetch it one phase ahead
+                const f4* src = A.hsave + ((size_t)htask * 10 + 2 * (l - 1)) * 64 + lane;
+                if constexpr (XYZ) { C.h[l - 1][0] = src[0]; C.h[l - 1][1] = src[64]; }
+                else { CC.h[l - 1][0] = src[0]; CC.h[l - 1][1] = src[64]; }
+            }
             if constexpr (XYZ) {
                 gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);                 // g_c += fc[l]^T g_h
                 // ---- phase FC_l: G = g_h, X = c ------------------------------------------------------------
@@ -430,10 +433,6 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         NSK_PH(9); NSK_PHI(9);
         if (it + 1 < iters) {
             stage_b(nx);
-            if constexpr (FWD_LDS) {
-                lds_barrier();                        // every wave is done with the backward image
-                for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.img[i];
-            }
         }
         NSK_PH(17); NSK_PHI(17);
         if (scat) scatter_tile_faces(A.grid, T, gc, lane, valid, scratch);

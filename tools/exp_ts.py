@@ -33,6 +33,7 @@ def report(tag, flags=3):
             out.append("r%d[%d wg] end med %.1f max %.1f" % (role, m.sum(), np.median(e), e.max()))
     print(" | ".join(out))
 
+ctx.set_matmul_mode(0)
 report("base")
 lib.nsk_dbg_set(ctx.h, 1); report("no_atomics(loop kept)")
 lib.nsk_dbg_set(ctx.h, 0); report("no_scatter", 3 | (1 << 9))

@@ -31,17 +31,18 @@ PEAK_HBM_GBS = 8000.0              # same guide, HBM3E peak
 MAC = {
     "decode_fwd_coarse": 6176, "decode_fwd_middle": 15479, "decode_fwd_fine": 20599, "decode_fwd_color": 15575,
     "decode_bwd_coarse": 6176, "decode_bwd_middle": 9248, "decode_bwd_fine": 9248, "decode_bwd_color": 9344,
-    # trainable: forward recompute + input gradients + embedding-gradient products + weight gradients
-    "decode_bwd_coarse_train": 6176 * 3, "decode_bwd_middle_train": 15479 + 9248 + 5952 + 15479,
-    "decode_bwd_fine_train": 20599 + 9248 + 5952 + 20599, "decode_bwd_color_train": 15575 + 9344 + 5952 + 15575,
+    # trainable: input gradients + embedding-gradient products + weight gradients (block outputs come from the forward, which
+    # saved them: no recompute; the fine decoder still recomputes its forward)
+    "decode_bwd_coarse_train": 6176 * 2, "decode_bwd_middle_train": 9248 + 5952 + 15479,
+    "decode_bwd_fine_train": 20599 + 9248 + 5952 + 20599, "decode_bwd_color_train": 9344 + 5952 + 15575,
 }
 # algorithmic HBM bytes per sample of each kernel: 8 corners x 32 ch x 4 B per level read, 2x that per level
 # scattered (read-modify-write), plus per-sample intermediates
 BYTES = {
     "decode_fwd_coarse": 1024 + 8, "decode_fwd_middle": 1024 + 8, "decode_fwd_fine": 2048 + 8, "decode_fwd_color": 1024 + 20,
     "decode_bwd_coarse": 2048 + 20, "decode_bwd_middle": 2048 + 52, "decode_bwd_fine": 2048 + 52, "decode_bwd_color": 2048 + 52,
-    "decode_bwd_coarse_train": 3072 + 20, "decode_bwd_middle_train": 3072 + 20, "decode_bwd_fine_train": 4096 + 20,
-    "decode_bwd_color_train": 3072 + 20,
+    "decode_bwd_coarse_train": 3072 + 20 + 640, "decode_bwd_middle_train": 3072 + 20 + 640, "decode_bwd_fine_train": 4096 + 20,
+    "decode_bwd_color_train": 3072 + 20 + 640,          # + the 160 saved block outputs read back
 }
 
 
@@ -161,17 +162,17 @@ def main():
     per_kernel = {k: {"launches": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in prof.items()}
     # merged launches: all decoders of the stage run as workgroup roles of one kernel
     MAC["decode_fwd_multi"] = MAC["decode_fwd_middle"] + MAC["decode_fwd_fine"] + (MAC["decode_fwd_color"] if args.stage == "color" else 0)
-    BYTES["decode_fwd_multi"] = BYTES["decode_fwd_middle"] + BYTES["decode_fwd_fine"] + (BYTES["decode_fwd_color"] if args.stage == "color" else 0)
+    BYTES["decode_fwd_multi"] = BYTES["decode_fwd_middle"] + BYTES["decode_fwd_fine"] + (BYTES["decode_fwd_color"] + 640 if args.stage == "color" else 0)
     MAC["decode_bwd_multi"] = MAC["decode_bwd_middle"] + MAC["decode_bwd_fine"] + (MAC["decode_bwd_color_train"] if args.stage == "color" else 0)
     BYTES["decode_bwd_multi"] = BYTES["decode_bwd_middle"] + BYTES["decode_bwd_fine"] + (BYTES["decode_bwd_color_train"] if args.stage == "color" else 0)
     dom = max((k for k in prof if k.startswith("decode")), key=lambda k: prof[k][1])
     dom_s = prof[dom][1] / prof[dom][0] * 1e-3
     flops = 2.0 * MAC[dom] * M
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    # (profiles/r01c_pmc_hbm.json, tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the
+    # (profiles/r01d_pmc_hbm.json, tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the
     # MI355X guide prescribes for gfx950).  Only valid for the default 1000-ray workload the passes were run on.
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01c_pmc_hbm.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01d_pmc_hbm.json")
     if os.path.exists(pmc_path) and N == 1000 and args.stage == "color":
         pmc = json.load(open(pmc_path))
         prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "k_decode_fwd_multi_bf16"}.get(dom)
@@ -182,8 +183,8 @@ def main():
             "frac": flops / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
             "avg_launch_us": dom_s * 1e6, "alg_flops_per_launch": flops,
             "alg_bytes_per_launch": BYTES[dom] * M, "hbm_frac_same_kernel": BYTES[dom] * M / dom_s / 1e9 / PEAK_HBM_GBS}
-    step_bytes = 9221.0 * M + 28.0 * sum(sc["grids"][k].size for k in ("middle", "fine", "color"))
-    step_flops = 238e3 * M
+    step_bytes = (9221.0 + 1280.0) * M + 28.0 * sum(sc["grids"][k].size for k in ("middle", "fine", "color"))   # + saved block outputs, written and read
+    step_flops = 2.0 * (MAC["decode_fwd_multi"] + MAC["decode_bwd_multi"]) * M + 1000.0 * M                    # + sampling / compositing
     out = {
         "metric": "mapping rays/sec (and ms/iter) on CoFusion room1 at 1/2/4/8 MI355X",
         "value": world * N * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

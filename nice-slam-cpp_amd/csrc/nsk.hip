@@ -467,6 +467,7 @@ struct DecState {
     int* fidx = nullptr; int* bidx = nullptr;
     int* finv = nullptr; int* binv = nullptr;     // inverse of fidx / bidx: image position of each canonical parameter
     int* inv16 = nullptr;                         // inverse of fidx16
+    float* bimg16 = nullptr; int* bidx16 = nullptr; int bfrag16_n = 0; bool bimg16_dirty = true;   // bf16 3-piece backward image (frozen chain), repacked lazily
     float* fimg16 = nullptr; int* fidx16 = nullptr; int frag16_n = 0, fimg16_f = 0, tail_off = 0, tail16_off = 0;   // bf16 3-piece forward image
     int fimg_n = 0, bimg_n = 0;
     int trainable = 0;
@@ -601,7 +602,7 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
     for (int i = 0; i < 4; ++i) {
         hipFree(c->grid[i].v); hipFree(c->grid[i].m); hipFree(c->grid[i].s); hipFree(c->grid[i].mask);
         hipFree(c->dec[i].p); hipFree(c->dec[i].m); hipFree(c->dec[i].s); hipFree(c->dec[i].fimg); hipFree(c->dec[i].bimg);
-        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv); hipFree(c->dec[i].inv16);
+        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv); hipFree(c->dec[i].inv16); hipFree(c->dec[i].bimg16); hipFree(c->dec[i].bidx16);
         hipFree(c->dec[i].fimg16); hipFree(c->dec[i].fidx16);
     }
     hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal); hipFree(c->fr_tmp);
@@ -801,6 +802,32 @@ static void build_idx16(const DecLayout& L, std::vector<int>& idx)
     seg16(idx, I::W3E, 3, L.oW[3], 125, 0, NSK_E); seg16(idx, I::W3H, 1, L.oW[3], 125, NSK_E, 32);
 }
 
+static void build_idx16b(const DecLayout& L, std::vector<int>& idx)
+{
+    idx.assign((size_t)MlpBwdImgB::NFG * 512, -1);
+    auto seg = [&](int fg0, int Wofs, int ld, int col0) {        // transposed: row o = input column, k = output row of the forward weight
+        for (int rt = 0; rt < 2; ++rt) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+            const int o = 16 * rt + (lane & 15), k = nsk_bf16_kperm(lane >> 4, j);
+            idx[((size_t)(fg0 + rt) * 64 + lane) * 8 + j] = Wofs + k * ld + col0 + o;
+        }
+    };
+    for (int l = 0; l < 5; ++l) seg(MlpBwdImgB::FT(l), L.oFw[l], L.c_dim, 0);
+    for (int l = 1; l < 5; ++l) seg(MlpBwdImgB::WT(l), L.oW[l], L.in_dim[l], l == 3 ? NSK_E : 0);
+}
+
+// the frozen chain's bf16 backward image follows the parameters lazily: marked stale by uploads and Adam steps, rebuilt before use
+static int ensure_bimg16(nsk_ctx* c, int w)
+{
+    DecState& D = c->dec[w];
+    if (!D.bimg16 || !D.bimg16_dirty) return 0;
+    ProfScope ps(c, "pack_bwd_bf16");
+    k_pack_bf16<<<(D.bfrag16_n + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<unsigned short*>(D.bimg16), D.bidx16, D.p, D.bfrag16_n);
+    k_pack<<<1, 128, 0, c->stream>>>(D.bimg16 + MlpBwdImgB::P_WO, D.bidx + MlpBwdImg::P_WO, D.p, 128);
+    HIPCHK(hipGetLastError());
+    D.bimg16_dirty = false;
+    return 0;
+}
+
 static int repack16(nsk_ctx* c, int w)
 {
     DecState& D = c->dec[w];
@@ -819,6 +846,7 @@ static int repack(nsk_ctx* c, int w)
     k_pack<<<(D.bimg_n + 255) / 256, 256, 0, c->stream>>>(D.bimg, D.bidx, D.p, D.bimg_n);
     HIPCHK(hipGetLastError());
     CHK(repack16(c, w));
+    D.bimg16_dirty = true;
     return 0;
 }
 
@@ -852,6 +880,12 @@ extern "C" int nsk_decoder_upload(nsk_ctx* c, int w, const float* h, size_t n)
             HIPCHK(hipMalloc(&D.fimg16, (size_t)D.fimg16_f * 4)); HIPCHK(hipMalloc(&D.fidx16, i16.size() * 4));
             HIPCHK(hipMemset(D.fimg16, 0, (size_t)D.fimg16_f * 4));
             HIPCHK(hipMemcpy(D.fidx16, i16.data(), i16.size() * 4, hipMemcpyHostToDevice));
+            std::vector<int> ib;
+            build_idx16b(nsk_dec_layout(w), ib);
+            D.bfrag16_n = (int)ib.size();
+            HIPCHK(hipMalloc(&D.bimg16, (size_t)MlpBwdImgB::TOTAL_F * 4)); HIPCHK(hipMalloc(&D.bidx16, ib.size() * 4));
+            HIPCHK(hipMemset(D.bimg16, 0, (size_t)MlpBwdImgB::TOTAL_F * 4));
+            HIPCHK(hipMemcpy(D.bidx16, ib.data(), ib.size() * 4, hipMemcpyHostToDevice));
             std::vector<int> inv16(n4, -1);
             for (size_t k = 0; k < i16.size(); ++k) if (i16[k] >= 0) { if (inv16[i16[k]] != -1) return fail("decoder %d: parameter %d appears twice in the bf16 image", w, i16[k]); inv16[i16[k]] = (int)k; }
             HIPCHK(hipMalloc(&D.inv16, n4 * 4));
@@ -974,6 +1008,7 @@ static void fill_args(nsk_ctx* c, DecArgs& A, int w, int M, int S, const float* 
     A.bimg = reinterpret_cast<const f4*>(c->dec[w].bimg);
     A.img_f4 = c->dec[w].fimg_n / 4;
     A.img16 = c->dec[w].fimg16;
+    A.bimg16 = c->dec[w].bimg16;
     A.out = w == 3 ? c->ws.rgb4 : c->ws.occ[w];
 }
 
@@ -1011,6 +1046,7 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     A.g_rays_o = g_ro; A.g_rays_d = g_rd;
     A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
     A.flags = flags;
+    if (!train && w != 0 && !rays) CHK(ensure_bimg16(c, w));
     if (train && w != 2) {
         if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
         A.hsave = c->ws.hsave[w];
@@ -1257,6 +1293,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         A.g_rays_o = g_ro; A.g_rays_d = g_rd;
         A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
         A.flags = (flags & 0xffu) | (M >= 96000 ? 256u : 0u);       // bit 8: face-sharing scatter in the frozen roles
+        if (!train && w != 0 && !rays) CHK(ensure_bimg16(c, w));
         if (train && w != 2) {
             if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
             A.hsave = c->ws.hsave[w];
@@ -1623,6 +1660,7 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
             adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, S.step_size, S.bc2s);
             S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.mask = nullptr; S.n = n4;
             S.inv_f = D.finv; S.inv_b = D.binv; S.fimg = D.fimg; S.bimg = D.bimg;
+            D.bimg16_dirty = true;
             if (c->pend_w == w) {
                 S.slabs = c->ws.dec_slabs; S.nslabs = c->pend_nb; S.slab_stride = n4; c->pend_w = -1;
                 blocks += (n4 / 4 + 31) / 32 - (n4 / 4 + 255) / 256;       // 32 float4 per block (see k_adam_multi)

@@ -16,8 +16,6 @@
 #pragma once
 #include "nsk_device.h"
 
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-
 template <int CQ>
 struct MlpFwdImgB {                               // block (K=32) indices of the segments; fragment group = 2*blk + rt
     static constexpr int CB = CQ / 2;
@@ -47,23 +45,6 @@ struct MlpFwdImgB {                               // block (K=32) indices of the
 
 __host__ __device__ inline int nsk_bf16_kperm(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); }
 
-// split fp32 -> three bf16 pieces (round to nearest even each; the residual of one piece feeds the next)
-struct B3 { bf8 h, m, l; };
-__device__ __forceinline__ B3 split_block(f4 q0, f4 q1)
-{
-    B3 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = j < 4 ? q0[j] : q1[j - 4];
-        const __bf16 h = (__bf16)x;
-        const float r1 = x - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        r.h[j] = h; r.m[j] = m; r.l[j] = (__bf16)r2;
-    }
-    return r;
-}
-
 // image build: one thread per (fragment group, lane, j); idx = canonical parameter offset or -1
 __global__ void k_pack_bf16(unsigned short* __restrict__ img, const int* __restrict__ idx, const float* __restrict__ P, int n)
 {
@@ -80,26 +61,6 @@ __global__ void k_pack_bf16(unsigned short* __restrict__ img, const int* __restr
     img[base] = __builtin_bit_cast(unsigned short, h);
     img[base + 64 * 8] = __builtin_bit_cast(unsigned short, m);
     img[base + 128 * 8] = __builtin_bit_cast(unsigned short, l);
-}
-
-struct Frag3 { bf8 h, m, l; };
-__device__ __forceinline__ Frag3 load_frag(const bf8* __restrict__ img, int fg, int lane)
-{
-    const bf8* b = img + (size_t)fg * 3 * 64 + lane;
-    Frag3 f; f.h = b[0]; f.m = b[64]; f.l = b[128];
-    return f;
-}
-__device__ __forceinline__ f4 mfma_b(bf8 a, bf8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-
-// acc[rt] += W[16rt.., block] x  (six bf16 products per output tile)
-__device__ __forceinline__ void mac_block(const Frag3& a0, const Frag3& a1, const B3& x, f4 (&acc)[2])
-{
-    acc[0] = mfma_b(a0.h, x.h, acc[0]); acc[1] = mfma_b(a1.h, x.h, acc[1]);
-    acc[0] = mfma_b(a0.h, x.m, acc[0]); acc[1] = mfma_b(a1.h, x.m, acc[1]);
-    acc[0] = mfma_b(a0.m, x.h, acc[0]); acc[1] = mfma_b(a1.m, x.h, acc[1]);
-    acc[0] = mfma_b(a0.h, x.l, acc[0]); acc[1] = mfma_b(a1.h, x.l, acc[1]);
-    acc[0] = mfma_b(a0.l, x.h, acc[0]); acc[1] = mfma_b(a1.l, x.h, acc[1]);
-    acc[0] = mfma_b(a0.m, x.m, acc[0]); acc[1] = mfma_b(a1.m, x.m, acc[1]);
 }
 
 // static schedule (see FwdSched): step s multiplies weight block blk[s] with input block xs[s]

@@ -222,6 +222,64 @@ __device__ __forceinline__ void tri_gather(const GridD& G, const Tri& T, int g, 
     }
 }
 
+// ---- bf16 3-piece split helpers (the scheme is described in nsk_bf16.h) -------------------------------
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+// split fp32 -> three bf16 pieces (round to nearest even each; the residual of one piece feeds the next)
+struct B3 { bf8 h, m, l; };
+__device__ __forceinline__ B3 split_block(f4 q0, f4 q1)
+{
+    B3 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? q0[j] : q1[j - 4];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        r.h[j] = h; r.m[j] = m; r.l[j] = (__bf16)r2;
+    }
+    return r;
+}
+
+struct Frag3 { bf8 h, m, l; };
+__device__ __forceinline__ Frag3 load_frag(const bf8* __restrict__ img, int fg, int lane)
+{
+    const bf8* b = img + (size_t)fg * 3 * 64 + lane;
+    Frag3 f; f.h = b[0]; f.m = b[64]; f.l = b[128];
+    return f;
+}
+__device__ __forceinline__ f4 mfma_b(bf8 a, bf8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// acc[rt] += W[16rt.., block] x  (six bf16 products per output tile)
+__device__ __forceinline__ void mac_block(const Frag3& a0, const Frag3& a1, const B3& x, f4 (&acc)[2])
+{
+    acc[0] = mfma_b(a0.h, x.h, acc[0]); acc[1] = mfma_b(a1.h, x.h, acc[1]);
+    acc[0] = mfma_b(a0.h, x.m, acc[0]); acc[1] = mfma_b(a1.h, x.m, acc[1]);
+    acc[0] = mfma_b(a0.m, x.h, acc[0]); acc[1] = mfma_b(a1.m, x.h, acc[1]);
+    acc[0] = mfma_b(a0.h, x.l, acc[0]); acc[1] = mfma_b(a1.h, x.l, acc[1]);
+    acc[0] = mfma_b(a0.l, x.h, acc[0]); acc[1] = mfma_b(a1.l, x.h, acc[1]);
+    acc[0] = mfma_b(a0.m, x.m, acc[0]); acc[1] = mfma_b(a1.m, x.m, acc[1]);
+}
+
+
+// backward (transposed) image of an MLP decoder in bf16 pieces, for the frozen-decoder chain without ray gradients:
+// fragment group FT(l) + rt: fc[l]^T rows 16rt.. (grid features 0..31), WT(l) + rt: pts_linear[l]^T (h part), K = 32 each
+struct MlpBwdImgB {
+    static constexpr int NFG = 18;
+    static constexpr int FRAG_BYTES = NFG * 3 * 1024;
+    static constexpr int P_WO = FRAG_BYTES / 4;      // float offset of the output weight [4][32]
+    static constexpr int TOTAL_F = P_WO + 128;
+    __host__ __device__ static constexpr int FT(int l) { return 2 * l; }
+    __host__ __device__ static constexpr int WT(int l) { return 10 + 2 * (l - 1); }
+};
+// acc[rt] += (fragment groups fg0, fg0+1) x   (six bf16 MFMAs per row tile)
+__device__ __forceinline__ void gemm_b(const bf8* __restrict__ img, int fg0, int lane, const B3& x, f4 (&acc)[2])
+{
+    const Frag3 a0 = load_frag(img, fg0, lane), a1 = load_frag(img, fg0 + 1, lane);
+    mac_block(a0, a1, x, acc);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // A-fragment GEMM: acc[rt] += W[16rt.., :] x  for an input of KQ quads (D layout) -- see nsk_layout.h
 // ------------------------------------------------------------------------------------------------------
@@ -438,6 +496,7 @@ struct DecArgs {
     const f4* img;            // forward image (global)
     const void* img16;        // bf16 3-piece forward image (nsk_bf16.h) or nullptr
     const f4* bimg;           // backward image (global)
+    const void* bimg16;       // bf16 3-piece backward image (MlpBwdImgB) or nullptr
     int img_f4;               // forward image size in f4
     float* out;               // occupancy [M] (which<3) or rgb4 [M][4] (color)
     unsigned long long* masks;   // [M][4] ReLU bits or nullptr
@@ -904,18 +963,25 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     constexpr bool XYZ = WHICH != 0;
     constexpr int OD = WHICH == 3 ? 4 : 1;
     constexpr bool NEED_E = XYZ && RAYS;
-    constexpr int IMG_F = XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL;
+    // B16: without ray gradients an MLP decoder's chain is ten K=32 products per tile; they run on the bf16 matrix cores with
+    // 3-piece operands (fp32-accurate, nsk_bf16.h) instead of the fp32 MFMA, which blocks the SIMD's vector issue
+    constexpr bool B16 = XYZ && !RAYS;
+    constexpr int IMG_F = B16 ? MlpBwdImgB::TOTAL_F : (XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL);
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     float* scratch = smf + IMG_F + wave * 960;                  // per-wave scatter scratch (3840 B)
-    for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.bimg[i];
+    {
+        const f4* src = B16 ? reinterpret_cast<const f4*>(A.bimg16) : A.bimg;
+        for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = src[i];
+    }
     __syncthreads();
     const f4* bimg = smem;
+    const bf8* img16 = reinterpret_cast<const bf8*>(smem);
     const float* bimgf = reinterpret_cast<const float*>(smem);
     const float* Bm = nullptr;
-    if constexpr (XYZ) Bm = bimgf + MlpBwdImg::P_BM;
-    const float* Wo = XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO;
+    if constexpr (XYZ && !B16) Bm = bimgf + MlpBwdImg::P_BM;
+    const float* Wo = B16 ? bimgf + MlpBwdImgB::P_WO : (XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO);
 
     const int ntasks = (A.M + 15) >> 4;
     // The next tile's loads are issued at the top of this tile and forced to have landed before this tile's scatter: vmcnt
@@ -967,13 +1033,21 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
 #pragma unroll
         for (int l = 4; l >= 0; --l) {
-            if constexpr (XYZ) gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);            // g_c += fc[l]^T g_h
+            if constexpr (B16) { const B3 xg = split_block(gh[0], gh[1]); gemm_b(img16, MlpBwdImgB::FT(l), lane, xg, gc); }
+            else if constexpr (XYZ) gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);       // g_c += fc[l]^T g_h
             f4 ga[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
-            if constexpr (XYZ) {
+            if constexpr (B16) {
+                if (l >= 1) {
+                    const B3 xa = split_block(ga[0], ga[1]);
+                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
+                    gemm_b(img16, MlpBwdImgB::WT(l > 0 ? l : 1), lane, xa, ghn);
+                    gh[0] = ghn[0]; gh[1] = ghn[1];
+                }
+            } else if constexpr (XYZ) {
                 if constexpr (NEED_E) {
                     if (l == 3) gemm_e(bimg, MlpBwdImg::W3ET, lane, ga, ge);
                     if (l == 0) gemm_e(bimg, MlpBwdImg::W0ET, lane, ga, ge);

@@ -1299,9 +1299,9 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
             A.hsave = c->ws.hsave[w];
         }
         MA.which[n] = w; MA.train[n] = train ? 1 : 0;
-        // measured (1000 and 10000 rays, colour stage): ~65 us per 8-task iteration of the trainable role against ~10 us per
-        // task of a frozen role; 170 minimised decode_bwd_multi at both sizes (130: 159/1365 us, 170: 140/1155, 200: 193/1213)
-        static const int frozen_cost = getenv("NSK_FROZEN_COST") ? atoi(getenv("NSK_FROZEN_COST")) : 210;
+        // relative cost of one task of a frozen role against one 8-task iteration of the trainable role (= 1000); measured on
+        // decode_bwd_multi at 1000 / 4000 / 10000 rays: 170: 110/-/950 us, 190: 103/366/829, 210: 112/-/845, 250: 107/381/930
+        static const int frozen_cost = getenv("NSK_FROZEN_COST") ? atoi(getenv("NSK_FROZEN_COST")) : 190;
         cost[n] = train ? 1000 : frozen_cost;
         lds = std::max(lds, bwd_lds_bytes(w, train));
         if (train) train_role = train_role == -1 ? n : -2;     // -2: more than one trainable decoder -> separate launches below

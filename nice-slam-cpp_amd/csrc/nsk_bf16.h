@@ -145,15 +145,18 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
         Tri T;
         tri_setup(A.grid, A.bound, px, py, pz, T);
         Act<CQ> C;
-        tri_gather(A.grid, T, g, C.xc[0], C.xc[1]);
+        GatherRaw R;                                   // the gather's 16 loads are in flight while the embedding is computed
+        tri_gather_issue(A.grid, T, g, R);
+        sample_load(A, min((task + nb * NW) * 16 + j, A.M - 1), nx);      // unconditional (clamped): no branch, no wait here
+        f4 dummy[6];
+        embed<false>(imgf + I::P_BM, g, px, py, pz, C.xe, dummy);
+        asm volatile("" ::: "memory");                 // keep the order: loads, embedding, weighting
+        tri_gather_reduce(T, R, C.xc[0], C.xc[1]);
         if constexpr (WHICH == 2) {
             Tri Tm;
             tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
             tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
         }
-        sample_load(A, min((task + nb * NW) * 16 + j, A.M - 1), nx);      // unconditional (clamped): no branch, no wait here
-        f4 dummy[6];
-        embed<false>(imgf + I::P_BM, g, px, py, pz, C.xe, dummy);
         mlp_forward_bf16<CQ>(img, imgf, lane, C);
         float out[OD];
         mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);

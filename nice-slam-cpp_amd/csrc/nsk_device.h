@@ -280,6 +280,23 @@ __device__ __forceinline__ void gemm_b(const bf8* __restrict__ img, int fg0, int
     mac_block(a0, a1, x, acc);
 }
 
+// the same in two steps (loads first, weighting later) so that independent work can sit between them
+struct GatherRaw { f4 a[8], b[8]; };
+__device__ __forceinline__ void tri_gather_issue(const GridD& G, const Tri& T, int g, GatherRaw& R)
+{
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f4* vp = reinterpret_cast<const f4*>(G.v + (size_t)T.vox[c] * 32 + 4 * g);
+        R.a[c] = vp[0]; R.b[c] = vp[4];
+    }
+}
+__device__ __forceinline__ void tri_gather_reduce(const Tri& T, const GatherRaw& R, f4& c0, f4& c1)
+{
+    c0 = (f4)(0.f); c1 = (f4)(0.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { c0 += T.w[c] * R.a[c]; c1 += T.w[c] * R.b[c]; }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // A-fragment GEMM: acc[rt] += W[16rt.., :] x  for an input of KQ quads (D layout) -- see nsk_layout.h
 // ------------------------------------------------------------------------------------------------------

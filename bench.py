@@ -91,11 +91,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    # rehearsal of the N > 1 path on a one-GPU box: NSK_BENCH_REHEARSE=1 puts every rank on cuda:0 and exchanges over gloo
+    # (numbers from such a run mean nothing; the driver's multi-GPU run uses RCCL, one rank per GPU)
+    rehearse = os.environ.get("NSK_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import nice_slam_cpp_amd as pkg
     import scenes

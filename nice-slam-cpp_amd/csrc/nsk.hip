@@ -1292,7 +1292,8 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         A.g_raw = c->ws.g_raw;
         A.g_rays_o = g_ro; A.g_rays_d = g_rd;
         A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
-        A.flags = (flags & 0xffu) | (M >= 96000 ? 256u : 0u);       // bit 8: face-sharing scatter in the frozen roles
+        static const int faces_m = getenv("NSK_FACES_M") ? atoi(getenv("NSK_FACES_M")) : 96000;
+        A.flags = (flags & 0xffu) | (M >= faces_m ? 256u : 0u);     // bit 8: face-sharing scatter in the frozen roles
         if (!train && w != 0 && !rays) CHK(ensure_bimg16(c, w));
         if (train && w != 2) {
             if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);

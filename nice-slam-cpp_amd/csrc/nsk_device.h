@@ -1104,11 +1104,28 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             tri_grad_p(A.grid, T, g, gc, gp);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { gp[k] += __shfl_xor(gp[k], 16); gp[k] += __shfl_xor(gp[k], 32); }
-            if (g == 0 && valid && A.g_rays_o) {
+            if (A.g_rays_o) {
+                // the 16 samples of a tile usually belong to one ray (S = 48 = 3 tiles): sum them in the wave and add once; sixteen
+                // lanes adding to one address serialise (200 rays: the ray-gradient atomics were most of a 74 us kernel)
+                const int n0 = __builtin_amdgcn_readfirstlane(n);
+                if (__builtin_amdgcn_ballot_w64(valid && n != n0) == 0ull) {
+                    float a[6];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    atomicAdd(A.g_rays_o + 3 * n + k, gp[k]);
-                    atomicAdd(A.g_rays_d + 3 * n + k, gp[k] * zz);
+                    for (int k = 0; k < 3; ++k) { a[k] = valid ? gp[k] : 0.f; a[3 + k] = valid ? gp[k] * zz : 0.f; }
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) a[k] += __shfl_xor(a[k], o);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { atomicAdd(A.g_rays_o + 3 * n0 + k, a[k]); atomicAdd(A.g_rays_d + 3 * n0 + k, a[3 + k]); }
+                    }
+                } else if (g == 0 && valid) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        atomicAdd(A.g_rays_o + 3 * n + k, gp[k]);
+                        atomicAdd(A.g_rays_d + 3 * n + k, gp[k] * zz);
+                    }
                 }
             }
         }

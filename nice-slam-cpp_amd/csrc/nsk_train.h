@@ -422,11 +422,26 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             tri_grad_p(A.grid, T, g, gc, gp);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { gp[k] += __shfl_xor(gp[k], 16); gp[k] += __shfl_xor(gp[k], 32); }
-            if (g == 0 && valid && A.g_rays_o) {
+            if (A.g_rays_o) {        // one add per tile when its 16 samples share a ray (see decode_bwd_body)
+                const int n0 = __builtin_amdgcn_readfirstlane(n);
+                if (__builtin_amdgcn_ballot_w64(valid && n != n0) == 0ull) {
+                    float a[6];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    atomicAdd(A.g_rays_o + 3 * n + k, gp[k]);
-                    atomicAdd(A.g_rays_d + 3 * n + k, gp[k] * zz);
+                    for (int k = 0; k < 3; ++k) { a[k] = valid ? gp[k] : 0.f; a[3 + k] = valid ? gp[k] * zz : 0.f; }
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) a[k] += __shfl_xor(a[k], o);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { atomicAdd(A.g_rays_o + 3 * n0 + k, a[k]); atomicAdd(A.g_rays_d + 3 * n0 + k, a[3 + k]); }
+                    }
+                } else if (g == 0 && valid) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        atomicAdd(A.g_rays_o + 3 * n + k, gp[k]);
+                        atomicAdd(A.g_rays_d + 3 * n + k, gp[k] * zz);
+                    }
                 }
             }
         }

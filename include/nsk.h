@@ -111,7 +111,9 @@ size_t nsk_decoder_param_count(int which);
 int nsk_decoder_upload(nsk_ctx* ctx, int which, const float* h_packed, size_t n);
 int nsk_decoder_download(nsk_ctx* ctx, int which, float* h_packed, size_t n);
 int nsk_decoder_grad_download(nsk_ctx* ctx, int which, float* h_packed, size_t n);
-/* which decoders receive gradients / Adam updates (src/Mapper.cpp:292-301: fine if !fix_fine, color if !fix_color) */
+/* which decoders receive gradients / Adam updates (src/Mapper.cpp:292-301: fine if !fix_fine, color if !fix_color).  Set it
+ * before the forward of the step: the forward of a trainable decoder stores its block outputs for the backward (the entry points
+ * that contain both -- nsk_map_step, nsk_track_step, nsk_render_backward -- always do); a backward that finds them stale fails. */
 int nsk_decoder_set_trainable(nsk_ctx* ctx, int which, int trainable);
 
 /* ---- rendering ------------------------------------------------------------------------------------------ */

@@ -119,7 +119,12 @@ __global__ __launch_bounds__(256) void k_sample(RParams R, int N, int S, const f
     const int ns = R.n_samples;
     const int nsurf = S - ns;
     const float gt = has_gt ? gt_depth[n] : 0.f;
-    const float gmax = gtmax_dev ? *gtmax_dev : gtmax_host;
+    float gmax = gtmax_dev ? *gtmax_dev : gtmax_host;
+    if (has_gt && !gtmax_dev && gtmax_host < 0.f) {         // batch maximum computed by every wave itself (small batches: one launch fewer)
+        float mx = -NSK_INF;
+        for (int i = lane; i < N; i += 64) mx = fmaxf(mx, gt_depth[i]);
+        gmax = wave_max(mx);
+    }
     const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
     const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
     float near = has_gt ? mul_rn(gt, 0.01f) : 0.01f;                        // :57,:63

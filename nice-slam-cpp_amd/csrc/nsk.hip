@@ -1310,9 +1310,10 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         if (grids) c->touched[NSK_GROUP_COARSE + w] = true;
         ++n;
     }
-    if ((n == 0 || train_role == -2) && d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
+    static const int separate = getenv("NSK_BWD_SEPARATE") ? atoi(getenv("NSK_BWD_SEPARATE")) : 0;     // experiment: one launch per decoder (measured: no faster)
+    if ((n == 0 || train_role == -2 || separate) && d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
     if (n == 0) return 0;
-    if (train_role == -2) {      // rare configuration (several trainable decoders share one slab buffer): one launch each
+    if (train_role == -2 || separate) {      // rare configuration (several trainable decoders share one slab buffer): one launch each
         for (int r = 0; r < n; ++r)
             CHK(launch_decode_bwd(c, MA.which[r], M, S, ro, rd, MA.train[r] != 0, rays, flags, g_ro, g_rd));
         return 0;

@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--rays", type=int, default=1000, help="rays per GPU per step (config/nice_slam.yaml mapping.pixels)")
     ap.add_argument("--stage", default="color")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay each batch's step as a captured hipGraph (single GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -136,6 +137,15 @@ def main():
                 nd.allreduce_grads(ctx.grad_slab())              # step's pending gradient reductions before it is read
             ctx.adam_step(lr)
 
+        if args.graph and world == 1:                           # one graph per batch of the pool, replayed instead of re-issued
+            step(0)                                              # sizes the workspaces
+            gids = []
+            for b in range(len(batches)):
+                ctx.graph_begin(); step(b); gids.append(ctx.graph_end())
+            eager_step = step
+
+            def step(i):                                         # noqa: F811
+                ctx.graph_launch(gids[i % len(gids)])
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
@@ -157,7 +167,7 @@ def main():
         # per-kernel durations: HIP events recorded on the context's stream around every launch (same steps again)
         ctx.profile_begin()
         for i in range(args.steps):
-            step(args.warmup + i)
+            (eager_step if args.graph and world == 1 else step)(args.warmup + i)      # events are recorded around eager launches
         prof = ctx.profile_end()
         final_loss = float(loss)
 

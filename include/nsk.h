@@ -204,6 +204,17 @@ int nsk_adam_vector(nsk_ctx* ctx, int n, float* d_p, const float* d_g, float* d_
  * re-creates the optimiser on every optimize_map call, :330). */
 int nsk_adam_step(nsk_ctx* ctx, const float lr[NSK_NUM_GROUPS], float beta1, float beta2, float eps);
 int nsk_adam_reset(nsk_ctx* ctx);
+
+/* ---- hipGraph capture of a step ------------------------------------------------------------------------------
+ * The kernels of the nsk_* calls made between nsk_graph_begin and nsk_graph_end (e.g. nsk_map_step + nsk_adam_step with fixed
+ * device buffers, sizes, learning rates and a device-computed or fixed gt_depth_max) are recorded instead of run, and
+ * nsk_graph_launch replays them with one launch on the context's stream; Adam's step counts advance per replay (the recorded
+ * Adam node is patched with the new bias-correction constants).  Run the step once eagerly first (workspaces are sized then);
+ * at most one nsk_adam_step per graph; calls that synchronise (uploads, downloads, nsk_grad_slab) are not capturable. */
+int nsk_graph_begin(nsk_ctx* ctx);
+int nsk_graph_end(nsk_ctx* ctx, int* graph_id);
+int nsk_graph_launch(nsk_ctx* ctx, int graph_id);
+int nsk_graph_destroy(nsk_ctx* ctx, int graph_id);
 int nsk_zero_grads(nsk_ctx* ctx);
 
 /* ---- multi-GPU ------------------------------------------------------------------------------------------- */

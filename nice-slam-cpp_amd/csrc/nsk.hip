@@ -499,6 +499,15 @@ struct nsk_ctx {
     float* scal = nullptr;       // [0] gt max, [1] median threshold, [2] loss, [4] frustum max depth (bits)
     void* fr_tmp = nullptr; size_t fr_cap = 0;      // nsk_frustum_mask scratch
     int adam_step[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
+    // ---- hipGraph capture of a step (nsk_graph_*): the kernels of the calls made between begin and end are recorded once and
+    // replayed with one launch; Adam's bias-correction constants are kernel arguments, so the recorded k_adam_multi node is
+    // patched with the current step counts before every replay
+    bool capturing = false;
+    struct CapAdam { AdamArgs args; int group[8]; float lr[8]; };
+    std::vector<CapAdam> cap_adams;             // Adam launches seen during the current capture
+    int cap_rollback[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
+    struct GraphRec { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t adam_node = nullptr; bool has_adam = false; CapAdam adam; };
+    std::vector<GraphRec> graphs;
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
     int matmul_mode = 1;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split (fp32-accurate, nsk_bf16.h)
@@ -851,6 +860,7 @@ static int repack(nsk_ctx* c, int w)
 }
 
 static int flush_pending(nsk_ctx* c);
+static void adam_consts(float lr, float b1, float b2, int step, float& step_size, float& bc2s);
 
 extern "C" size_t nsk_decoder_param_count(int which) { return which_ok(which) ? (size_t)nsk_dec_layout(which).total : 0; }
 
@@ -942,6 +952,7 @@ static int ensure_ws(nsk_ctx* c, int N, int M)
 {
     Workspace& w = c->ws;
     if (M <= w.capM && N <= w.capN) return 0;
+    if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
     HIPCHK(hipStreamSynchronize(c->stream));
     int capM = std::max(M, w.capM), capN = std::max(N, w.capN);
     free_ws(w);
@@ -967,6 +978,7 @@ static int ensure_hsave(nsk_ctx* c, int w, int M)
     Workspace& ws = c->ws;
     const size_t tiles = (size_t)(M + 15) / 16 + 1;
     if (tiles > ws.hcap[w]) {
+        if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
         HIPCHK(hipStreamSynchronize(c->stream));
         hipFree(ws.hsave[w]);
         HIPCHK(hipMalloc(&ws.hsave[w], tiles * 10 * 64 * sizeof(f4)));
@@ -1641,11 +1653,14 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
     PackArgs PA; memset(&PA, 0, sizeof(PA));
     AA.b1 = b1; AA.b2 = b2; AA.eps = eps;
     int blocks = 0, pblocks = 0;
+    int seg_group[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int lv = 0; lv < 4; ++lv) {
         int grp = NSK_GROUP_COARSE + lv;
         if (!c->touched[grp] || !c->grid[lv].n) continue;
         int step = ++c->adam_step[grp];
+        if (c->capturing) ++c->cap_rollback[grp];
         GridState& G = c->grid[lv];
+        seg_group[AA.n] = grp;
         AdamSeg& S = AA.s[AA.n++];
         adam_consts(lr[grp], b1, b2, step, S.step_size, S.bc2s);
         S.p = G.v; S.g = c->slab + G.g_off; S.m = G.m; S.v = G.s; S.mask = G.mask; S.n = (int)G.n;
@@ -1654,10 +1669,12 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
     }
     if (c->touched[NSK_GROUP_DECODERS]) {
         int step = ++c->adam_step[NSK_GROUP_DECODERS];
+        if (c->capturing) ++c->cap_rollback[NSK_GROUP_DECODERS];
         for (int w = 0; w < 4; ++w) {
             DecState& D = c->dec[w];
             if (!D.trainable || !D.loaded) continue;
             int n4 = (D.n + 3) & ~3;
+            seg_group[AA.n] = NSK_GROUP_DECODERS;
             AdamSeg& S = AA.s[AA.n++];
             adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, S.step_size, S.bc2s);
             S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.mask = nullptr; S.n = n4;
@@ -1672,9 +1689,92 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
         }
         c->touched[NSK_GROUP_DECODERS] = false;
     }
+    if (AA.n && c->capturing) {
+        nsk_ctx::CapAdam ca; ca.args = AA;
+        for (int i = 0; i < AA.n; ++i) { ca.group[i] = seg_group[i]; ca.lr[i] = lr[seg_group[i]]; }
+        c->cap_adams.push_back(ca);
+    }
     if (AA.n) { ProfScope ps(c, "adam_multi"); k_adam_multi<<<blocks, 256, 0, c->stream>>>(AA); }
     if (PA.n) { ProfScope ps(c, "pack_images"); k_pack_multi<<<pblocks, 256, 0, c->stream>>>(PA); }
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- hipGraph capture (see nsk_ctx::GraphRec) ---------------------------------------------------------------------
+extern "C" int nsk_graph_begin(nsk_ctx* c)
+{
+    if (!c) return fail("null ctx");
+    if (c->capturing) return fail("nsk_graph_begin: a capture is already open");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(flush_pending(c));
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    c->cap_adams.clear();
+    for (int g = 0; g < NSK_NUM_GROUPS; ++g) c->cap_rollback[g] = 0;
+    return 0;
+}
+
+extern "C" int nsk_graph_end(nsk_ctx* c, int* graph_id)
+{
+    if (!c || !graph_id) return fail("nsk_graph_end: null argument");
+    if (!c->capturing) return fail("nsk_graph_end: no capture is open");
+    c->capturing = false;
+    nsk_ctx::GraphRec R;
+    hipError_t e = hipStreamEndCapture(c->stream, &R.graph);
+    for (int g = 0; g < NSK_NUM_GROUPS; ++g) c->adam_step[g] -= c->cap_rollback[g];      // nothing ran during the capture
+    c->pend_w = -1;
+    if (e != hipSuccess || !R.graph) return fail("nsk_graph_end: hipStreamEndCapture: %s", hipGetErrorString(e));
+    if (c->cap_adams.size() > 1) { hipGraphDestroy(R.graph); return fail("nsk_graph_end: at most one nsk_adam_step per captured graph"); }
+    if (!c->cap_adams.empty()) {
+        R.has_adam = true; R.adam = c->cap_adams[0];
+        size_t nn = 0;
+        HIPCHK(hipGraphGetNodes(R.graph, nullptr, &nn));
+        std::vector<hipGraphNode_t> nodes(nn);
+        HIPCHK(hipGraphGetNodes(R.graph, nodes.data(), &nn));
+        for (hipGraphNode_t nd : nodes) {
+            hipGraphNodeType t;
+            HIPCHK(hipGraphNodeGetType(nd, &t));
+            if (t != hipGraphNodeTypeKernel) continue;
+            hipKernelNodeParams kp;
+            HIPCHK(hipGraphKernelNodeGetParams(nd, &kp));
+            if (kp.func == reinterpret_cast<void*>(k_adam_multi)) R.adam_node = nd;
+        }
+        if (!R.adam_node) { hipGraphDestroy(R.graph); return fail("nsk_graph_end: the Adam kernel node was not found in the captured graph"); }
+    }
+    HIPCHK(hipGraphInstantiate(&R.exec, R.graph, nullptr, nullptr, 0));
+    c->graphs.push_back(R);
+    *graph_id = (int)c->graphs.size() - 1;
+    return 0;
+}
+
+extern "C" int nsk_graph_launch(nsk_ctx* c, int id)
+{
+    if (!c || id < 0 || id >= (int)c->graphs.size() || !c->graphs[id].exec) return fail("nsk_graph_launch: bad graph id %d", id);
+    HIPCHK(hipSetDevice(c->device));
+    nsk_ctx::GraphRec& R = c->graphs[id];
+    if (R.has_adam) {                            // this replay is one more Adam step for the groups the graph updates
+        AdamArgs& A = R.adam.args;
+        int stepped[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < A.n; ++i) {
+            const int g = R.adam.group[i];
+            if (!stepped[g]) { ++c->adam_step[g]; stepped[g] = 1; }
+            adam_consts(R.adam.lr[i], A.b1, A.b2, c->adam_step[g], A.s[i].step_size, A.s[i].bc2s);
+        }
+        hipKernelNodeParams kp;
+        HIPCHK(hipGraphKernelNodeGetParams(R.adam_node, &kp));
+        void* args[1] = {&A};
+        kp.kernelParams = args; kp.extra = nullptr;
+        HIPCHK(hipGraphExecKernelNodeSetParams(R.exec, R.adam_node, &kp));
+    }
+    HIPCHK(hipGraphLaunch(R.exec, c->stream));
+    return 0;
+}
+
+extern "C" int nsk_graph_destroy(nsk_ctx* c, int id)
+{
+    if (!c || id < 0 || id >= (int)c->graphs.size()) return fail("nsk_graph_destroy: bad graph id %d", id);
+    nsk_ctx::GraphRec& R = c->graphs[id];
+    if (R.exec) { HIPCHK(hipStreamSynchronize(c->stream)); hipGraphExecDestroy(R.exec); hipGraphDestroy(R.graph); R.exec = nullptr; R.graph = nullptr; }
     return 0;
 }
 

@@ -22,7 +22,7 @@ SYMBOLS = (
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
     "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
-    "nsk_adam_reset", "nsk_zero_grads", "nsk_grad_slab", "nsk_allreduce_grads", "nsk_last_call_stats",
+    "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_grad_slab", "nsk_allreduce_grads", "nsk_last_call_stats",
     "nsk_profile_begin", "nsk_profile_end",
 )
 
@@ -384,6 +384,21 @@ class Context:
         _chk(lib().nsk_adam_step(self.h, arr, C.c_float(b1), C.c_float(b2), C.c_float(eps)))
 
     @_ordered
+    def graph_begin(self):
+        """record (instead of run) the kernels of the following calls; call from inside `with torch.cuda.stream(ctx.tstream)`"""
+        _chk(lib().nsk_graph_begin(self.h))
+
+    def graph_end(self):
+        gid = C.c_int(-1)
+        _chk(lib().nsk_graph_end(self.h, C.byref(gid)))
+        return gid.value
+
+    def graph_launch(self, gid):
+        _chk(lib().nsk_graph_launch(self.h, gid))
+
+    def graph_destroy(self, gid):
+        _chk(lib().nsk_graph_destroy(self.h, gid))
+
     def adam_reset(self):
         _chk(lib().nsk_adam_reset(self.h))
 

@@ -432,3 +432,35 @@ def test_backward_with_several_iterations_per_workgroup(oracle32, oracle64):
     for k, (got, ref, ref64) in out.items():
         e, e64, eo = rel_l2(got, ref), rel_l2(got, ref64), rel_l2(ref, ref64)
         assert e < 5 * TOL or e64 < 2 * eo + TOL, "%s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (k, e, e64, eo)
+
+
+def test_graph_replay_matches_eager_steps(oracle32):
+    """hipGraph capture of a mapping step (nsk_graph_begin / end / launch): three replays must leave the same optimised state as
+    three eager steps (up to the order of the atomic adds), including Adam's per-step bias correction"""
+    sc = _scene(23, grid_std=0.05)
+    rays = scenes.make_rays(24, 300, sc["bound"], n_frames=2)
+    ro, rd, gd, gc = cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"]), cu(rays["gt_color"])
+    lr = [0.005, 0.0, 0.005, 0.005, 0.005, 0.0]
+    out = {}
+    for mode in ("eager", "graph"):
+        ctx = make_ctx(sc, trainable=["color"])
+        loss = torch.zeros(1, device="cuda")
+        with torch.cuda.stream(ctx.tstream):
+            def step():
+                ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.2, True, flags=3, loss=loss)
+                ctx.adam_step(lr)
+            step()                                   # step 1 eagerly in both (sizes the workspaces)
+            if mode == "eager":
+                step(); step(); step()
+            else:
+                ctx.graph_begin(); step(); gid = ctx.graph_end()
+                for _ in range(3):
+                    ctx.graph_launch(gid)
+                ctx.graph_destroy(gid)
+        ctx.sync()
+        out[mode] = ({k: ctx.grid_download(k) for k in ("middle", "fine", "color")}, ctx.decoder_download("color"), float(loss))
+    for k in ("middle", "fine", "color"):
+        assert np.abs(out["eager"][0][k] - sc["grids"][k]).max() > 1e-3
+        assert rel_l2(out["graph"][0][k], out["eager"][0][k]) < 1e-5, k
+    assert rel_l2(out["graph"][1], out["eager"][1]) < 1e-5
+    assert abs(out["graph"][2] - out["eager"][2]) < 1e-4 * abs(out["eager"][2])

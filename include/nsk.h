@@ -184,6 +184,14 @@ int nsk_gather_pixels(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t
                       const float* d_color, float* d_gt_depth, float* d_gt_color);
 int nsk_rays_from_pixels(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy,
                          float cx, float cy, const float* d_c2w, int mode, float* d_rays_o, float* d_rays_d);
+/* fused forms for a device-resident Tracker iteration (same arithmetic as the calls they replace, fewer launches):
+ * nsk_rays_from_camera = nsk_camera_from_tensor + nsk_rays_from_pixels (d_c2w_out: optional 12 floats);
+ * nsk_pose_step = nsk_rays_backward + nsk_camera_backward + nsk_adam_vector on the 7-vector (d_g_cam_out: optional 7 floats). */
+int nsk_rays_from_camera(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy, float cx, float cy,
+                         const float* d_cam, int mode, float* d_rays_o, float* d_rays_d, float* d_c2w_out);
+int nsk_pose_step(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy, float cx, float cy, int mode,
+                  const float* d_g_rays_o, const float* d_g_rays_d, float* d_cam, float* d_m, float* d_v, float lr, float b1, float b2,
+                  float eps, int step, float* d_g_cam_out);
 /* d loss / d c2w (12 floats, overwritten) from per-ray gradients */
 int nsk_rays_backward(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy,
                       float cx, float cy, int mode, const float* d_g_rays_o, const float* d_g_rays_d, float* d_g_c2w);

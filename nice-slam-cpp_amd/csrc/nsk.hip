@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_rays_backward(int n, const int* pi, con
 }
 
 // quad2rotation / get_camera_from_tensor, reference include/torchlib/utils.h:174-210
-__global__ void k_camera_from_tensor(const float* cam, float* c2w)
+__device__ __forceinline__ void camera_matrix(const float* cam, float* c2w)
 {
     float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
     float two_s = 2.f / (qr * qr + qi * qi + qj * qj + qk * qk);
@@ -265,8 +265,9 @@ __global__ void k_camera_from_tensor(const float* cam, float* c2w)
                   two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1.f - two_s * (qi * qi + qj * qj)};
     for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) c2w[4 * a + b] = R[3 * a + b]; c2w[4 * a + 3] = cam[4 + a]; }
 }
+__global__ void k_camera_from_tensor(const float* cam, float* c2w) { camera_matrix(cam, c2w); }
 
-__global__ void k_camera_backward(const float* cam, const float* g_c2w, float* g_cam)
+__device__ __forceinline__ void camera_matrix_backward(const float* cam, const float* g_c2w, float* g_cam)
 {
     float q[4] = {cam[0], cam[1], cam[2], cam[3]};
     float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
@@ -283,6 +284,60 @@ __global__ void k_camera_backward(const float* cam, const float* g_c2w, float* g
         g_cam[c] = s;
     }
     for (int a = 0; a < 3; ++a) g_cam[4 + a] = g_c2w[4 * a + 3];
+}
+__global__ void k_camera_backward(const float* cam, const float* g_c2w, float* g_cam) { camera_matrix_backward(cam, g_c2w, g_cam); }
+
+// Fused forms for a device-resident Tracker iteration (each removes launches of ~6 us from a ~70 us, launch-bound iteration):
+// pose 7-vector -> c2w -> rays in one kernel; ray gradients -> d c2w -> d pose -> Adam on the pose in one single-block kernel.
+__global__ void k_rays_from_camera(int n, const int* pi, const int* pj, float fx, float fy, float cx, float cy, const float* cam, int mode,
+                                   float* ro, float* rd, float* c2w_out)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float c2w[12];
+    camera_matrix(cam, c2w);
+    if (r == 0 && c2w_out) for (int k = 0; k < 12; ++k) c2w_out[k] = c2w[k];
+    if (r >= n) return;
+    float i = (float)pi[r], j = (float)pj[r];
+    float d0 = div_rn(sub_rn(i, cx), fx);
+    float d1 = (mode & 1) ? div_rn(sub_rn(i, cy), fy) : -div_rn(sub_rn(j, cy), fy);
+    float d2 = -1.f;
+    for (int a = 0; a < 3; ++a) {
+        rd[3 * r + a] = add_rn(add_rn(mul_rn(d0, c2w[4 * a]), mul_rn(d1, c2w[4 * a + 1])), mul_rn(d2, c2w[4 * a + 2]));
+        ro[3 * r + a] = c2w[4 * a + 3];
+    }
+}
+__global__ __launch_bounds__(256) void k_pose_step(int n, const int* pi, const int* pj, float fx, float fy, float cx, float cy, int mode,
+                                                   const float* g_ro, const float* g_rd, float* cam, float* m, float* v, float step_size,
+                                                   float bc2s, float b1, float b2, float eps, float* g_cam_out)
+{
+    __shared__ float sh[4][12];
+    __shared__ float g_c2w[12];
+    float acc[12];
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        float i = (float)pi[r], j = (float)pj[r];
+        float dir[3] = {(i - cx) / fx, (mode & 1) ? (i - cy) / fy : -(j - cy) / fy, -1.f};
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) acc[4 * a + b] += g_rd[3 * r + a] * dir[b];
+            acc[4 * a + 3] += g_ro[3 * r + a];
+        }
+    }
+    for (int k = 0; k < 12; ++k) { float s = wave_sum(acc[k]); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = s; }
+    __syncthreads();
+    if (threadIdx.x < 12) g_c2w[threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float g[7];
+        camera_matrix_backward(cam, g_c2w, g);
+        for (int k = 0; k < 7; ++k) {              // k_adam_scalar's update
+            float gg = g[k];
+            float mm = b1 * m[k] + (1.f - b1) * gg;
+            float vv = b2 * v[k] + (1.f - b2) * gg * gg;
+            cam[k] -= step_size * (mm / (sqrtf(vv) / bc2s + eps));
+            m[k] = mm; v[k] = vv;
+            if (g_cam_out) g_cam_out[k] = gg;
+        }
+    }
 }
 
 __global__ void k_inside_filter(RParams R, int N, const float* ro, const float* rd, const float* gt, uint8_t* keep)
@@ -505,8 +560,10 @@ struct nsk_ctx {
     bool capturing = false;
     struct CapAdam { AdamArgs args; int group[8]; float lr[8]; };
     std::vector<CapAdam> cap_adams;             // Adam launches seen during the current capture
+    struct CapVec { int n; float* p; const float* g; float* m; float* v; float lr, b1, b2, eps; int step; hipGraphNode_t node; float ss, bc2s; };
+    std::vector<CapVec> cap_vecs;               // nsk_adam_vector launches seen during the current capture
     int cap_rollback[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
-    struct GraphRec { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t adam_node = nullptr; bool has_adam = false; CapAdam adam; };
+    struct GraphRec { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t adam_node = nullptr; bool has_adam = false; CapAdam adam; std::vector<CapVec> vecs; };
     std::vector<GraphRec> graphs;
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
@@ -1620,6 +1677,26 @@ extern "C" int nsk_camera_backward(nsk_ctx* c, const float* cam, const float* g_
     HIPCHK(hipGetLastError());
     return 0;
 }
+extern "C" int nsk_rays_from_camera(nsk_ctx* c, int n, const int32_t* pi, const int32_t* pj, float fx, float fy, float cx, float cy,
+                                    const float* d_cam, int mode, float* ro, float* rd, float* d_c2w_out)
+{
+    if (!c || !pi || !pj || !d_cam || !ro || !rd || n < 1) return fail("nsk_rays_from_camera: bad argument");
+    intr(mode, fx, fy, cx, cy);
+    k_rays_from_camera<<<(n + 255) / 256, 256, 0, c->stream>>>(n, pi, pj, fx, fy, cx, cy, d_cam, mode, ro, rd, d_c2w_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int nsk_pose_step(nsk_ctx* c, int n, const int32_t* pi, const int32_t* pj, float fx, float fy, float cx, float cy, int mode,
+                             const float* g_ro, const float* g_rd, float* d_cam, float* d_m, float* d_v, float lr, float b1, float b2, float eps,
+                             int step, float* d_g_cam_out)
+{
+    if (!c || !pi || !pj || !g_ro || !g_rd || !d_cam || !d_m || !d_v || n < 1 || step < 1) return fail("nsk_pose_step: bad argument");
+    intr(mode, fx, fy, cx, cy);
+    float ss, bc2s; adam_consts(lr, b1, b2, step, ss, bc2s);
+    k_pose_step<<<1, 256, 0, c->stream>>>(n, pi, pj, fx, fy, cx, cy, mode, g_ro, g_rd, d_cam, d_m, d_v, ss, bc2s, b1, b2, eps, d_g_cam_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 extern "C" int nsk_inside_filter(nsk_ctx* c, int N, const float* ro, const float* rd, const float* gt, uint8_t* keep)
 {
     if (!c || !ro || !rd || !gt || !keep || N < 1) return fail("nsk_inside_filter: bad argument");
@@ -1639,6 +1716,7 @@ extern "C" int nsk_adam_vector(nsk_ctx* c, int n, float* p, const float* g, floa
 {
     if (!c || !p || !g || !m || !v || n < 1 || step < 1) return fail("nsk_adam_vector: bad argument");
     float ss, bc2s; adam_consts(lr, b1, b2, step, ss, bc2s);
+    if (c->capturing) c->cap_vecs.push_back(nsk_ctx::CapVec{n, p, g, m, v, lr, b1, b2, eps, step, nullptr, ss, bc2s});
     k_adam_scalar<<<(n + 255) / 256, 256, 0, c->stream>>>(n, p, g, m, v, ss, bc2s, b1, b2, eps);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1709,7 +1787,7 @@ extern "C" int nsk_graph_begin(nsk_ctx* c)
     CHK(flush_pending(c));
     HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     c->capturing = true;
-    c->cap_adams.clear();
+    c->cap_adams.clear(); c->cap_vecs.clear();
     for (int g = 0; g < NSK_NUM_GROUPS; ++g) c->cap_rollback[g] = 0;
     return 0;
 }
@@ -1725,8 +1803,9 @@ extern "C" int nsk_graph_end(nsk_ctx* c, int* graph_id)
     c->pend_w = -1;
     if (e != hipSuccess || !R.graph) return fail("nsk_graph_end: hipStreamEndCapture: %s", hipGetErrorString(e));
     if (c->cap_adams.size() > 1) { hipGraphDestroy(R.graph); return fail("nsk_graph_end: at most one nsk_adam_step per captured graph"); }
-    if (!c->cap_adams.empty()) {
-        R.has_adam = true; R.adam = c->cap_adams[0];
+    R.vecs = c->cap_vecs;
+    if (!c->cap_adams.empty()) { R.has_adam = true; R.adam = c->cap_adams[0]; }
+    if (R.has_adam || !R.vecs.empty()) {
         size_t nn = 0;
         HIPCHK(hipGraphGetNodes(R.graph, nullptr, &nn));
         std::vector<hipGraphNode_t> nodes(nn);
@@ -1738,8 +1817,11 @@ extern "C" int nsk_graph_end(nsk_ctx* c, int* graph_id)
             hipKernelNodeParams kp;
             HIPCHK(hipGraphKernelNodeGetParams(nd, &kp));
             if (kp.func == reinterpret_cast<void*>(k_adam_multi)) R.adam_node = nd;
+            if (kp.func == reinterpret_cast<void*>(k_adam_scalar) && kp.kernelParams)
+                for (auto& V : R.vecs) if (!V.node && *reinterpret_cast<float**>(kp.kernelParams[1]) == V.p) { V.node = nd; break; }
         }
-        if (!R.adam_node) { hipGraphDestroy(R.graph); return fail("nsk_graph_end: the Adam kernel node was not found in the captured graph"); }
+        if (R.has_adam && !R.adam_node) { hipGraphDestroy(R.graph); return fail("nsk_graph_end: the Adam kernel node was not found in the captured graph"); }
+        for (auto& V : R.vecs) if (!V.node) { hipGraphDestroy(R.graph); return fail("nsk_graph_end: an nsk_adam_vector node was not found in the captured graph"); }
     }
     HIPCHK(hipGraphInstantiate(&R.exec, R.graph, nullptr, nullptr, 0));
     c->graphs.push_back(R);
@@ -1765,6 +1847,15 @@ extern "C" int nsk_graph_launch(nsk_ctx* c, int id)
         void* args[1] = {&A};
         kp.kernelParams = args; kp.extra = nullptr;
         HIPCHK(hipGraphExecKernelNodeSetParams(R.exec, R.adam_node, &kp));
+    }
+    for (auto& V : R.vecs) {                      // the pose (or any plain vector) Adam: one more step per replay
+        adam_consts(V.lr, V.b1, V.b2, V.step, V.ss, V.bc2s);
+        ++V.step;
+        hipKernelNodeParams kp;
+        HIPCHK(hipGraphKernelNodeGetParams(V.node, &kp));
+        void* args[10] = {&V.n, &V.p, &V.g, &V.m, &V.v, &V.ss, &V.bc2s, &V.b1, &V.b2, &V.eps};
+        kp.kernelParams = args; kp.extra = nullptr;
+        HIPCHK(hipGraphExecKernelNodeSetParams(R.exec, V.node, &kp));
     }
     HIPCHK(hipGraphLaunch(R.exec, c->stream));
     return 0;

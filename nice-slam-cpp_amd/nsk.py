@@ -17,7 +17,7 @@ GROUP_DECODERS, GROUP_COARSE, GROUP_MIDDLE, GROUP_FINE, GROUP_COLOR, GROUP_CAMER
 # every symbol include/nsk.h declares
 SYMBOLS = (
     "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
-    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap", "nsk_sample_pixels", "nsk_gather_pixels",
+    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap", "nsk_sample_pixels", "nsk_gather_pixels", "nsk_rays_from_camera", "nsk_pose_step",
     "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
@@ -341,6 +341,25 @@ class Context:
         _chk(lib().nsk_rays_from_pixels(self.h, n, _ptr(pix_i), _ptr(pix_j), C.c_float(fx), C.c_float(fy), C.c_float(cx),
                                         C.c_float(cy), _ptr(c2w), mode, _ptr(ro), _ptr(rd)))
         return ro, rd
+
+    @_ordered
+    def rays_from_camera(self, pix_i, pix_j, intr, cam, mode=0):
+        """camera_from_tensor + rays_from_pixels in one launch -> (rays_o, rays_d)"""
+        import torch
+        n = pix_i.shape[0]
+        ro = torch.empty(n, 3, device=cam.device); rd = torch.empty(n, 3, device=cam.device)
+        fx, fy, cx, cy = intr
+        _chk(lib().nsk_rays_from_camera(self.h, n, _ptr(pix_i), _ptr(pix_j), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                        _ptr(cam), mode, _ptr(ro), _ptr(rd), None))
+        return ro, rd
+
+    @_ordered
+    def pose_step(self, pix_i, pix_j, intr, g_ro, g_rd, cam, m, v, lr, step, mode=0, b1=0.9, b2=0.999, eps=1e-8, g_cam_out=None):
+        """rays_backward + camera_backward + adam_vector on the pose in one launch (cam, m, v updated in place)"""
+        fx, fy, cx, cy = intr
+        _chk(lib().nsk_pose_step(self.h, pix_i.shape[0], _ptr(pix_i), _ptr(pix_j), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                 mode, _ptr(g_ro), _ptr(g_rd), _ptr(cam), _ptr(m), _ptr(v), C.c_float(lr), C.c_float(b1), C.c_float(b2),
+                                 C.c_float(eps), int(step), _ptr(g_cam_out)))
 
     @_ordered
     def rays_backward(self, pix_i, pix_j, intr, g_ro, g_rd, mode=0):

@@ -464,3 +464,30 @@ def test_graph_replay_matches_eager_steps(oracle32):
         assert rel_l2(out["graph"][0][k], out["eager"][0][k]) < 1e-5, k
     assert rel_l2(out["graph"][1], out["eager"][1]) < 1e-5
     assert abs(out["graph"][2] - out["eager"][2]) < 1e-4 * abs(out["eager"][2])
+
+
+def test_fused_pose_kernels_equal_their_parts():
+    """nsk_rays_from_camera = camera_from_tensor + rays_from_pixels and nsk_pose_step = rays_backward + camera_backward +
+    adam_vector: same arithmetic, so the same bits (the parts are checked against the oracle in test_losses_and_pose_kernels)"""
+    sc = scenes.make_scene(1, grid_shapes=scenes.SMALL_GRID_SHAPES)
+    ctx = make_ctx(sc)
+    rng = np.random.default_rng(9)
+    n = 333
+    pi = cu(rng.integers(0, 640, n), torch.int32); pj = cu(rng.integers(0, 480, n), torch.int32)
+    intr = (360.0, 355.0, 320.5, 239.5)
+    cam = cu(np.array([0.9, 0.2, -0.3, 0.1, 0.5, -0.2, 0.4], np.float32))
+    for mode in (0, 1, 2):
+        c2w = ctx.camera_from_tensor(cam)
+        ro, rd = ctx.rays_from_pixels(pi, pj, intr, c2w, mode)
+        ro2, rd2 = ctx.rays_from_camera(pi, pj, intr, cam, mode)
+        assert torch.equal(ro, ro2) and torch.equal(rd, rd2)
+    g_ro = cu(rng.standard_normal((n, 3))); g_rd = cu(rng.standard_normal((n, 3)))
+    cam_a, m_a, v_a = cam.clone(), cu(rng.random(7) * 0.1), cu(rng.random(7) * 0.01)
+    cam_b, m_b, v_b = cam_a.clone(), m_a.clone(), v_a.clone()
+    for step in (3, 4):
+        g_cam = ctx.camera_backward(cam_a, ctx.rays_backward(pi, pj, intr, g_ro, g_rd))
+        ctx.adam_vector(cam_a, g_cam, m_a, v_a, 1e-2, step)
+        g_out = torch.zeros(7, device="cuda")
+        ctx.pose_step(pi, pj, intr, g_ro, g_rd, cam_b, m_b, v_b, 1e-2, step, g_cam_out=g_out)
+        assert torch.equal(g_out, g_cam)
+        assert torch.equal(cam_a, cam_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b)

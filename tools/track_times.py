@@ -35,5 +35,34 @@ with torch.cuda.stream(ctx.tstream):
     for s in range(26, 126): it(s)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 100
+    # fused pose kernels: 8 launches instead of 11
+    def it_fused(step):
+        ro, rd = ctx.rays_from_camera(pi, pj, r["intr"], cam)
+        ctx.track_step("color", ro, rd, gd, gc, -1.0, 0.5, True, True, True, flags=4, loss=loss, g_rays=(g_ro, g_rd))
+        ctx.pose_step(pi, pj, r["intr"], g_ro, g_rd, cam, m, v, 1e-3, step)
+    for s in range(200, 210): it_fused(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(210, 310): it_fused(s)
+    torch.cuda.synchronize()
+    dtf = (time.perf_counter() - t0) / 100
+    # the same iteration as one captured hipGraph (tensors created while capturing are kept alive: their addresses are recorded)
+    keep = []
+    def it_keep(step):
+        c = ctx.camera_from_tensor(cam)
+        ro, rd = ctx.rays_from_pixels(pi, pj, r["intr"], c)
+        ctx.track_step("color", ro, rd, gd, gc, -1.0, 0.5, True, True, True, flags=4, loss=loss, g_rays=(g_ro, g_rd))
+        g_c2w = ctx.rays_backward(pi, pj, r["intr"], g_ro, g_rd)
+        g_cam = ctx.camera_backward(cam, g_c2w)
+        ctx.adam_vector(cam, g_cam, m, v, 1e-3, step)
+        keep.extend([c, ro, rd, g_c2w, g_cam])
+    ctx.graph_begin(); it_keep(126); gid = ctx.graph_end()
+    for s in range(10): ctx.graph_launch(gid)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(100): ctx.graph_launch(gid)
+    torch.cuda.synchronize()
+    dtg = (time.perf_counter() - t0) / 100
 d = {k: round(1e3 * ms / c, 1) for k, (c, ms) in p.items()}
+print("graph replay: wall per iteration %.1f us; fused pose kernels: %.1f us; loss %.4f" % (dtg * 1e6, dtf * 1e6, float(loss)))
 print("rays", N, "wall per iteration %.1f us" % (dt * 1e6), "profiled kernels sum %.1f us" % sum(d.values()), d, "loss %.4f" % float(loss))

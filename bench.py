@@ -79,8 +79,8 @@ def cpu_baseline(sc, rays_list, lr, w_color, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=1000, help="rays per GPU per step (config/nice_slam.yaml mapping.pixels)")
     ap.add_argument("--stage", default="color")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -187,10 +187,10 @@ def main():
     dom_s = prof[dom][1] / prof[dom][0] * 1e-3
     flops = 2.0 * MAC[dom] * M
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    # (profiles/r01e_pmc_hbm.json, tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the
+    # (profiles/r01f_pmc_hbm.json, tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the
     # MI355X guide prescribes for gfx950).  Only valid for the default 1000-ray workload the passes were run on.
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01e_pmc_hbm.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01f_pmc_hbm.json")
     if os.path.exists(pmc_path) and N == 1000 and args.stage == "color":
         pmc = json.load(open(pmc_path))
         prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "k_decode_fwd_multi_bf16"}.get(dom)

@@ -62,10 +62,20 @@ int nsk_sync(nsk_ctx* ctx);                         /* hipStreamSynchronize */
 void* nsk_stream(nsk_ctx* ctx);                     /* the hipStream_t in use */
 
 /* How the decoders' matrix products are evaluated (results agree to fp32 rounding):
- *   0 = v_mfma_f32_16x16x4_f32, plain fp32 (default);
- *   1 = fp32 operands split into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation
- *       (forward decoders of multi-decoder stages; everything else stays in mode 0). */
+ *   1 = fp32 operands split into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation (DEFAULT;
+ *       forward of the MLP decoders in multi-decoder stages and the frozen decoders' backward chain without ray gradients);
+ *   0 = v_mfma_f32_16x16x4_f32, plain fp32, everywhere.
+ * The library reads no environment variables: this call and nsk_set_render_opts are the only behaviour switches. */
 int nsk_set_matmul_mode(nsk_ctx* ctx, int mode);
+
+/* Order in which the decoder kernels of a step walk the rays' samples (results differ only by the order of floating-point sums in the
+ * gradients): -1 = automatic (DEFAULT: cell-sorted for steps that scatter into the grids without ray gradients and have >= 2048 samples),
+ * 0 = ray order always, 1 = cell-sorted always.  Cell-sorted: k_sample also bins every sample by the grid cell it falls in and two small
+ * launches build the permutation; tiles of 16 samples then share cells and the backward issues one atomic flush per cell run. */
+int nsk_set_sort_mode(nsk_ctx* ctx, int mode);
+/* performance experiments only (never needed for correct results): key "frozen_cost" = relative cost of a frozen decoder's tile in the
+ * backward's workgroup split (0 = built-in value). */
+int nsk_set_tuning(nsk_ctx* ctx, const char* key, int value);
 
 /* Scene bound [[x0,x1],[y0,y1],[z0,z1]]; the reference hard-codes it in five places
  * (src/main.cpp:33, src/Renderer.cpp:15, src/Mapper.cpp:29, src/Tracker.cpp:23, src/models/MLP.cpp:53-56). */

@@ -539,6 +539,9 @@ struct Workspace {
     float* g_raw = nullptr; float* ray_loss = nullptr;
     float* tmp_rgb = nullptr; float* tmp_depth = nullptr; float* tmp_var = nullptr;
     float* dec_slabs = nullptr;      // per-workgroup partial decoder gradients [num_cu][20920]
+    // cell sort of the samples (k_sample keys -> k_sort_scan -> k_sort_place): perm lists the samples cell by cell
+    int* perm = nullptr; int* skey = nullptr; int* srank = nullptr;     // [capM]
+    int* hist = nullptr; int* offs = nullptr; size_t hist_cap = 0;       // [bins of the key level]; hist is zero between steps
 };
 struct nsk_ctx {
     int device = 0;
@@ -563,9 +566,12 @@ struct nsk_ctx {
     struct CapVec { int n; float* p; const float* g; float* m; float* v; float lr, b1, b2, eps; int step; hipGraphNode_t node; float ss, bc2s; };
     std::vector<CapVec> cap_vecs;               // nsk_adam_vector launches seen during the current capture
     int cap_rollback[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
-    struct GraphRec { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t adam_node = nullptr; bool has_adam = false; CapAdam adam; std::vector<CapVec> vecs; };
+    struct GraphRec { bool stale = false; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t adam_node = nullptr; bool has_adam = false; CapAdam adam; std::vector<CapVec> vecs; };
     std::vector<GraphRec> graphs;
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
+    int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
+    int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
+    bool sorted = false;                    // the current step's decoder launches walk the samples in cell-sorted order (ws.perm)
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
     int matmul_mode = 1;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split (fp32-accurate, nsk_bf16.h)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
@@ -591,6 +597,17 @@ struct ProfScope {      // records start/stop events around the launches issued 
     }
 };
 
+// Captured graphs hold raw pointers into the workspace, the gradient slab and the grids: whenever one of those buffers is
+// freed or reallocated every recorded graph becomes unusable and nsk_graph_launch must say so instead of replaying onto freed memory.
+static void invalidate_graphs(nsk_ctx* c)
+{
+    for (auto& R : c->graphs) {
+        if (R.exec) { hipGraphExecDestroy(R.exec); R.exec = nullptr; }
+        if (R.graph) { hipGraphDestroy(R.graph); R.graph = nullptr; }
+        R.stale = true;
+    }
+}
+
 extern "C" const char* nsk_last_error(void) { return g_err.c_str(); }
 extern "C" int nsk_version(void) { return NSK_VERSION; }
 
@@ -607,7 +624,7 @@ static size_t fwd_img_floats(int w) { return w == 0 ? CoarseFwdImg::TOTAL : (w =
 static size_t bwd_img_floats(int w) { return w == 0 ? CoarseBwdImg::TOTAL : MlpBwdImg::TOTAL; }
 static size_t bwd_lds_bytes(int w, bool train)
 {
-    size_t scratch = 8 * 3840;
+    size_t scratch = 8 * 3840;                               // 8 waves x (NSK_SCRATCH_FLOATS <= 960) floats
     if (!train) return bwd_img_floats(w) * 4 + scratch;
     size_t img = w == 2 ? 0 : bwd_img_floats(w);          // saved-activation form: only the backward image sits in LDS
     return (img + PN_FLOATS(w == 2 ? 4 : 2)) * 4;            // the per-wave scatter scratch lives in panel rows 0..63
@@ -646,7 +663,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
 #undef SETB
     CHK(set_lds(k_median_thr, 16384 * 4));
     CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024));
-    if (const char* e = getenv("NSK_MATMUL_MODE")) c->matmul_mode = atoi(e); CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
+    CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
     *out = c;
     return 0;
 }
@@ -657,6 +674,7 @@ static void free_ws(Workspace& w)
     for (int i = 0; i < 4; ++i) hipFree(w.masks[i]);
     for (int i = 0; i < 4; ++i) { hipFree(w.hsave[i]); w.hsave[i] = nullptr; w.hcap[i] = 0; w.hsave_M[i] = 0; }
     hipFree(w.g_raw); hipFree(w.ray_loss); hipFree(w.tmp_rgb); hipFree(w.tmp_depth); hipFree(w.tmp_var); hipFree(w.dec_slabs);
+    hipFree(w.perm); hipFree(w.skey); hipFree(w.srank); if (w.hist) hipFree(w.hist - 16); hipFree(w.offs);
     w = Workspace();
 }
 
@@ -689,6 +707,21 @@ extern "C" int nsk_set_matmul_mode(nsk_ctx* c, int mode)
     return 0;
 }
 
+extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
+{
+    if (!c || !key) return fail("nsk_set_tuning: null argument");
+    if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
+    return fail("nsk_set_tuning: unknown key '%s'", key);
+}
+
+extern "C" int nsk_set_sort_mode(nsk_ctx* c, int mode)
+{
+    if (!c) return fail("null ctx");
+    if (mode < -1 || mode > 1) return fail("nsk_set_sort_mode: mode must be -1 (automatic), 0 (never) or 1 (always)");
+    c->sort_mode = mode;
+    return 0;
+}
+
 extern "C" int nsk_set_bound(nsk_ctx* c, const float h_bound[6])
 {
     if (!c || !h_bound) return fail("nsk_set_bound: null argument");
@@ -717,6 +750,7 @@ static int rebuild_slab(nsk_ctx* c)
     n += 4;
     if (n != c->slab_n) {
         HIPCHK(hipStreamSynchronize(c->stream));
+        invalidate_graphs(c);
         if (c->slab) HIPCHK(hipFree(c->slab));
         HIPCHK(hipMalloc(&c->slab, n * sizeof(float)));
         c->slab_n = n;
@@ -737,10 +771,11 @@ extern "C" int nsk_grid_upload(nsk_ctx* c, int level, const float* h, int C, int
     bool realloc_ = n != G.n;
     if (realloc_) {
         HIPCHK(hipStreamSynchronize(c->stream));
+        invalidate_graphs(c);
         hipFree(G.v); hipFree(G.m); hipFree(G.s); hipFree(G.mask); G.mask = nullptr;
         HIPCHK(hipMalloc(&G.v, n * 4)); HIPCHK(hipMalloc(&G.m, n * 4)); HIPCHK(hipMalloc(&G.s, n * 4));
     }
-    if (G.Z != Z || G.Y != Y || G.X != X) { if (G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(G.mask); G.mask = nullptr; } }
+    if (G.Z != Z || G.Y != Y || G.X != X) { if (G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); invalidate_graphs(c); hipFree(G.mask); G.mask = nullptr; } }
     G.C = C; G.Z = Z; G.Y = Y; G.X = X; G.n = n;
     std::vector<float> t(n);
     for (int ch = 0; ch < 32; ++ch)
@@ -783,8 +818,8 @@ extern "C" int nsk_set_mask(nsk_ctx* c, int level, const uint8_t* h_mask)
     if (!G.n) return fail("nsk_set_mask: grid level %d not uploaded", level);
     HIPCHK(hipStreamSynchronize(c->stream));
     size_t nvox = G.n / 32;
-    if (!h_mask) { if (G.mask) { hipFree(G.mask); G.mask = nullptr; } return 0; }
-    if (!G.mask) HIPCHK(hipMalloc(&G.mask, nvox));
+    if (!h_mask) { if (G.mask) { invalidate_graphs(c); hipFree(G.mask); G.mask = nullptr; } return 0; }
+    if (!G.mask) { invalidate_graphs(c); HIPCHK(hipMalloc(&G.mask, nvox)); }
     HIPCHK(hipMemcpy(G.mask, h_mask, nvox, hipMemcpyHostToDevice));
     return 0;
 }
@@ -1011,6 +1046,7 @@ static int ensure_ws(nsk_ctx* c, int N, int M)
     if (M <= w.capM && N <= w.capN) return 0;
     if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
     HIPCHK(hipStreamSynchronize(c->stream));
+    invalidate_graphs(c);
     int capM = std::max(M, w.capM), capN = std::max(N, w.capN);
     free_ws(w);
     size_t m = (size_t)capM + 64;
@@ -1024,7 +1060,27 @@ static int ensure_ws(nsk_ctx* c, int N, int M)
     HIPCHK(hipMalloc(&w.tmp_rgb, n * 12)); HIPCHK(hipMalloc(&w.tmp_depth, n * 4)); HIPCHK(hipMalloc(&w.tmp_var, n * 4));
     HIPCHK(hipMalloc(&w.dec_slabs, (size_t)c->num_cu * 20920 * 4));
     HIPCHK(hipMemsetAsync(w.dec_slabs, 0, (size_t)c->num_cu * 20920 * 4, c->stream));
+    HIPCHK(hipMalloc(&w.perm, m * 4)); HIPCHK(hipMalloc(&w.skey, m * 4)); HIPCHK(hipMalloc(&w.srank, m * 4));
     w.capM = capM; w.capN = capN;
+    return 0;
+}
+
+// histogram / offsets of the cell sort: one bin per cell of the key level
+static int ensure_hist(nsk_ctx* c, size_t bins)
+{
+    Workspace& w = c->ws;
+    if (bins <= w.hist_cap) return 0;
+    if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    invalidate_graphs(c);
+    if (w.hist) hipFree(w.hist - 16);
+    hipFree(w.offs);
+    const size_t slots = ((bins / 8 + 1) / 2) * 16 + 16;    // hist_slot() layout (bins = 8 keys per cell) + one 64-byte line in front (hist[-1] = k_sort_scan's cursor)
+    int* raw = nullptr;
+    HIPCHK(hipMalloc(&raw, slots * 4)); HIPCHK(hipMalloc(&w.offs, bins * 4));
+    HIPCHK(hipMemsetAsync(raw, 0, slots * 4, c->stream));
+    w.hist = raw + 16;
+    w.hist_cap = bins;
     return 0;
 }
 
@@ -1037,6 +1093,7 @@ static int ensure_hsave(nsk_ctx* c, int w, int M)
     if (tiles > ws.hcap[w]) {
         if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
         HIPCHK(hipStreamSynchronize(c->stream));
+        invalidate_graphs(c);
         hipFree(ws.hsave[w]);
         HIPCHK(hipMalloc(&ws.hsave[w], tiles * 10 * 64 * sizeof(f4)));
         ws.hcap[w] = tiles;
@@ -1070,6 +1127,7 @@ static void fill_args(nsk_ctx* c, DecArgs& A, int w, int M, int S, const float* 
 {
     memset(&A, 0, sizeof(A));
     A.rays_o = ro; A.rays_d = rd; A.z = c->ws.z; A.pts = pts; A.M = M; A.S = S;
+    A.perm = (c->sorted && !pts) ? c->ws.perm : nullptr;
     memcpy(A.bound, c->R.bound, sizeof(A.bound));
     A.grid = grid_dev(c, w, false);
     if (w == 2) A.grid_mid = grid_dev(c, 1, false);
@@ -1239,9 +1297,25 @@ static void account(nsk_ctx* c, int stage, int M, int N, bool bwd, unsigned flag
 }
 
 // sampling + decoders of the stage; leaves z / occ / rgb4 (and ReLU bits) in the workspace
-static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax, bool save_masks)
+// The cell sort pays when the step scatters into the grids and does not need per-ray gradient sums (those rely on a tile's 16
+// samples sharing a ray: the Tracker and bundle adjustment keep the ray order)
+static bool sort_pays(nsk_ctx* c, int M, unsigned flags)
+{
+    return c->sort_mode == 1 ? true : (c->sort_mode == 0 ? false : ((flags & NSK_GRAD_GRIDS) && !(flags & NSK_GRAD_RAYS) && M >= 2048));
+}
+
+// sorted: the decoders of this step (forward and the backward that follows) walk the samples cell by cell (see k_sample)
+static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax, bool save_masks,
+                        bool sorted = false)
 {
     const int M = N * S;
+    c->sorted = sorted;
+    int key_level = 0;
+    for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) key_level = STAGE_DEC[stage][q];      // the finest level the stage reads
+    const GridState& KG = c->grid[key_level];
+    const GridState* PG = stage >= 2 ? &c->grid[1] : nullptr;      // parent level whose cells order the samples inside a key cell (k_sample)
+    const size_t bins = KG.n / 32 * 8;
+    if (sorted) CHK(ensure_hist(c, bins));
     const float* gmax_dev = nullptr;
     if (gt && gtmax < 0.f && N > 8192) {        // smaller batches: k_sample's waves take the maximum themselves
         ProfScope ps(c, "depth_max");
@@ -1250,7 +1324,13 @@ static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, co
     }
     {
     ProfScope ps(c, "sample");
-    k_sample<<<(N + 3) / 4, 256, 0, c->stream>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, c->ws.z);
+    k_sample<<<(N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS, 64 * NSK_SAMPLE_RAYS, 0, c->stream>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, c->ws.z, KG.X, KG.Y, KG.Z, PG ? PG->X : 0, PG ? PG->Y : 0, PG ? PG->Z : 0, (int)((bins / 8 + 1) / 2),
+                                                 sorted ? c->ws.skey : nullptr, c->ws.srank, c->ws.hist);
+    }
+    if (sorted) {
+        ProfScope ps(c, "cell_sort");
+        k_sort_scan<<<(int)((bins + 2047) / 2048), 256, 0, c->stream>>>((int)bins, (int)((bins / 8 + 1) / 2), c->ws.hist, c->ws.offs);
+        k_sort_place<<<(M + 255) / 256, 256, 0, c->stream>>>(M, c->ws.skey, c->ws.srank, c->ws.offs, c->ws.perm);
     }
     HIPCHK(hipGetLastError());
     CHK(launch_decode_fwd_stage(c, stage, M, S, ro, rd, save_masks));
@@ -1361,17 +1441,19 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         A.g_raw = c->ws.g_raw;
         A.g_rays_o = g_ro; A.g_rays_d = g_rd;
         A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
-        static const int faces_m = getenv("NSK_FACES_M") ? atoi(getenv("NSK_FACES_M")) : 96000;
-        A.flags = (flags & 0xffu) | (M >= faces_m ? 256u : 0u);     // bit 8: face-sharing scatter in the frozen roles
+#ifdef NSK_EXPERIMENT
+        A.flags = flags & 0xffffu;                                  // experiment builds pass the debug bits 9.. through (tools/exp_bwd.py)
+#else
+        A.flags = flags & 0xffu;
+#endif
         if (!train && w != 0 && !rays) CHK(ensure_bimg16(c, w));
         if (train && w != 2) {
             if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
             A.hsave = c->ws.hsave[w];
         }
         MA.which[n] = w; MA.train[n] = train ? 1 : 0;
-        // relative cost of one task of a frozen role against one 8-task iteration of the trainable role (= 1000); measured on
-        // decode_bwd_multi at 1000 / 4000 / 10000 rays: 170: 110/-/950 us, 190: 103/366/829, 210: 112/-/845, 250: 107/381/930
-        static const int frozen_cost = getenv("NSK_FROZEN_COST") ? atoi(getenv("NSK_FROZEN_COST")) : 190;
+        // relative cost of one tile of a frozen role against one 8-tile iteration of the trainable role (= 1000)
+        const int frozen_cost = c->tune_frozen_cost > 0 ? c->tune_frozen_cost : (c->sorted ? 150 : 190);
         cost[n] = train ? 1000 : frozen_cost;
         lds = std::max(lds, bwd_lds_bytes(w, train));
         if (train) train_role = train_role == -1 ? n : -2;     // -2: more than one trainable decoder -> separate launches below
@@ -1379,7 +1461,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         if (grids) c->touched[NSK_GROUP_COARSE + w] = true;
         ++n;
     }
-    static const int separate = getenv("NSK_BWD_SEPARATE") ? atoi(getenv("NSK_BWD_SEPARATE")) : 0;     // experiment: one launch per decoder (measured: no faster)
+    const int separate = 0;
     if ((n == 0 || train_role == -2 || separate) && d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
     if (n == 0) return 0;
     if (train_role == -2 || separate) {      // rare configuration (several trainable decoders share one slab buffer): one launch each
@@ -1415,7 +1497,7 @@ extern "C" int nsk_render_backward(nsk_ctx* c, int stage, int N, const float* ro
     CHK(common_checks(c, stage, N, ro, rd, &S, gt));
     if (!g_rgb || !g_depth) return fail("nsk_render_backward: g_rgb / g_depth is NULL");
     if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_render_backward: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
-    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true));
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, N * S, flags)));
     CompArgs A;
     comp_args(c, A, stage, N, S, ro, rd);
     A.mode = 1; A.g_rgb = g_rgb; A.g_depth = g_depth; A.g_var = g_var;
@@ -1436,7 +1518,7 @@ extern "C" int nsk_map_step(nsk_ctx* c, int stage, int N, const float* ro, const
     if (use_color && !gtc) return fail("nsk_map_step: use_color needs gt_color");
     CHK(common_checks(c, stage, N, ro, rd, &S, gt));
     if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_map_step: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
-    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true));
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, N * S, flags)));
     CompArgs A;
     comp_args(c, A, stage, N, S, ro, rd);
     A.mode = 2; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
@@ -1467,7 +1549,7 @@ extern "C" int nsk_track_step(nsk_ctx* c, int stage, int N, const float* ro, con
     if (use_color && !gtc) return fail("nsk_track_step: use_color needs gt_color");
     CHK(common_checks(c, stage, N, ro, rd, &S, gt));
     if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_track_step: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
-    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true));
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, N * S, flags)));
     CompArgs A;
     comp_args(c, A, stage, N, S, ro, rd);
     if (handle_dynamic) {                                      // forward pass for the median (Tracker.cpp:69-70)
@@ -1564,7 +1646,7 @@ extern "C" int nsk_frustum_mask(nsk_ctx* c, int level, const float* d_depth, int
     if (!G.n) return fail("nsk_frustum_mask: grid level %d not uploaded", level);
     HIPCHK(hipSetDevice(c->device));
     const size_t nvox = G.n / 32;
-    if (!G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMalloc(&G.mask, nvox)); }
+    if (!G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); invalidate_graphs(c); HIPCHK(hipMalloc(&G.mask, nvox)); }
     if (level == NSK_COARSE) {                                   // src/Mapper.cpp:54-59
         HIPCHK(hipMemsetAsync(G.mask, 1, nvox, c->stream));
     } else {
@@ -1831,7 +1913,9 @@ extern "C" int nsk_graph_end(nsk_ctx* c, int* graph_id)
 
 extern "C" int nsk_graph_launch(nsk_ctx* c, int id)
 {
-    if (!c || id < 0 || id >= (int)c->graphs.size() || !c->graphs[id].exec) return fail("nsk_graph_launch: bad graph id %d", id);
+    if (!c || id < 0 || id >= (int)c->graphs.size()) return fail("nsk_graph_launch: bad graph id %d", id);
+    if (c->graphs[id].stale) return fail("nsk_graph_launch: graph %d is stale -- a workspace, grid or gradient buffer it recorded was reallocated after the capture (larger batch, new grid shape or mask); capture it again", id);
+    if (!c->graphs[id].exec) return fail("nsk_graph_launch: graph %d was destroyed", id);
     HIPCHK(hipSetDevice(c->device));
     nsk_ctx::GraphRec& R = c->graphs[id];
     if (R.has_adam) {                            // this replay is one more Adam step for the groups the graph updates

@@ -135,11 +135,19 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
     const int ntasks = (A.M + 15) >> 4;
     // the sample loads (z, ray) of the next tile are issued before this tile's MLP: one of the two dependent L2 round
     // trips (z -> p -> gather) leaves the critical path (29 % of wave time was s_waitcnt, profiles/README.md)
+    // (with a cell-sorted launch the sample index is itself a load, A.perm: fetched two tiles ahead)
+    const int nw = nb * NW, wg = bid * NW + wave;
+    const int tsh = tile_shift(ntasks, nw);
+    const int kmax = tiles_per_wave(ntasks, nw, tsh);
     SampleRaw nx;
-    sample_load(A, min((bid * NW + wave) * 16 + j, A.M - 1), nx);
-    for (int task = bid * NW + wave; task < ntasks; task += nb * NW) {
+    int m = slot_sample(A, tile_of(0, wg, nw, tsh) * 16 + j);
+    sample_load(A, m, nx);
+    int m_next = slot_sample(A, tile_of(1, wg, nw, tsh) * 16 + j);
+    for (int k = 0; k < kmax; ++k) {
+        const int task = tile_of(k, wg, nw, tsh);
+        if (task >= ntasks) break;
         asm volatile("" ::: "memory");
-        const int m = task * 16 + j;
+        const int slot = task * 16 + j;
         float px, py, pz;
         sample_finish(A, nx, px, py, pz);
         Tri T;
@@ -147,7 +155,10 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
         Act<CQ> C;
         GatherRaw R;                                   // the gather's 16 loads are in flight while the embedding is computed
         tri_gather_issue(A.grid, T, g, R);
-        sample_load(A, min((task + nb * NW) * 16 + j, A.M - 1), nx);      // unconditional (clamped): no branch, no wait here
+        sample_load(A, m_next, nx);                    // unconditional (clamped): no branch, no wait here
+        const int m_cur = m;
+        m = m_next;
+        m_next = slot_sample(A, tile_of(k + 2, wg, nw, tsh) * 16 + j);
         f4 dummy[6];
         embed<false>(imgf + I::P_BM, g, px, py, pz, C.xe, dummy);
         asm volatile("" ::: "memory");                 // keep the order: loads, embedding, weighting
@@ -160,12 +171,12 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
         mlp_forward_bf16<CQ>(img, imgf, lane, C);
         float out[OD];
         mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);
-        if (m < A.M) {
+        if (slot < A.M) {
             if (g == 0) {
-                if constexpr (OD == 4) *reinterpret_cast<f4*>(A.out + (size_t)m * 4) = (f4){out[0], out[1], out[2], out[OD - 1]};
-                else A.out[m] = out[0];
+                if constexpr (OD == 4) *reinterpret_cast<f4*>(A.out + (size_t)m_cur * 4) = (f4){out[0], out[1], out[2], out[OD - 1]};
+                else A.out[m_cur] = out[0];
             }
-            if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
+            if (A.masks) A.masks[(size_t)slot * 4 + g] = C.mask;
         }
         if (A.hsave) save_h(A.hsave, task, lane, C.h);
     }

@@ -101,32 +101,67 @@ __global__ void k_depth_max(int N, const float* __restrict__ gt, float* __restri
     }
 }
 
+// histogram slot of a sort key (= cell * 8 + sub-bin): the 8 sub-bins of a cell stay together (32 bytes), but consecutive cells go
+// to different 64-byte lines (a line holds cells c and c + ncell2): same-line atomics serialise at the memory side and
+// neighbouring cells are hot together
+__device__ __forceinline__ int hist_slot(int key, int ncell2) { const int cell = key >> 3; return (((cell % ncell2) * 2 + cell / ncell2) << 3) + (key & 7); }
+
+// index of the grid cell (lower corner voxel, clamped into the grid) that holds world point p: the i0 of tri_setup below
+__device__ __forceinline__ int cell_index(int GX, int GY, int GZ, const float* bound, float px, float py, float pz)
+{
+    const int dims[3] = {GX, GY, GZ};
+    const float p[3] = {px, py, pz};
+    int i0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float lo = bound[2 * k], hi = bound[2 * k + 1];
+        float u = sub_rn(mul_rn(div_rn(sub_rn(p[k], lo), sub_rn(hi, lo)), 2.f), 1.f);
+        float x = mul_rn(div_rn(add_rn(u, 1.f), 2.f), (float)(dims[k] - 1));
+        float mx = (float)(dims[k] - 1);
+        if (x <= 0.f) x = 0.f;
+        else if (x >= mx) x = mx;
+        i0[k] = max(0, min((int)floorf(x), dims[k] - 1));
+    }
+    return (i0[2] * GY + i0[1]) * GX + i0[0];
+}
+
 // ------------------------------------------------------------------------------------------------------
 // K1: per-ray z sampling (reference src/Renderer.cpp:44-119).  One wave per ray, lane = sample slot.
 // z_out [N][S] sorted ascending.
+// Cell sort (optional, skey != nullptr): every sample also gets the index of the grid cell it falls in (grid kX x kY x kZ =
+// the finest level the stage reads) and its arrival rank inside that cell's histogram bin; k_sort_scan / k_sort_place turn
+// these into the permutation `perm` that lists the samples cell by cell.  The decoders then walk their 16-sample tiles
+// in that order, so that the samples of a tile share cells: the backward's scatter into the grid gradient sums them in
+// registers and issues one atomic flush per cell run instead of one per sample and cell (global float atomics run at
+// ~1.3 TB/s chip-wide and bounded the backward: DESIGN.md section 4).
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sample(RParams R, int N, int S, const float* __restrict__ rays_o,
+#define NSK_SAMPLE_RAYS 16          // rays (waves) per workgroup of k_sample
+#define NSK_SAMPLE_TABLE 2048       // slots of its cell table (>= 2 x NSK_SAMPLE_RAYS x 64 keeps probing short)
+__global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int N, int S, const float* __restrict__ rays_o,
                                                 const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
                                                 float gtmax_host, const float* __restrict__ gtmax_dev,
-                                                float* __restrict__ z_out)
+                                                float* __restrict__ z_out, int kX, int kY, int kZ, int pX, int pY, int pZ, int ncell2,
+                                                int* __restrict__ skey, int* __restrict__ srank, int* __restrict__ hist)
 {
-    __shared__ float sh[4][64];
-    __shared__ float sh2[4][64];
+    __shared__ float sh[NSK_SAMPLE_RAYS][64];
+    __shared__ float sh2[NSK_SAMPLE_RAYS][64];
+    __shared__ int tkey[NSK_SAMPLE_TABLE], tcnt[NSK_SAMPLE_TABLE], tbase[NSK_SAMPLE_TABLE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;                                 // whole wave exits together
+    const int n = blockIdx.x * NSK_SAMPLE_RAYS + wave;
+    const bool active = n < N;                          // whole waves; inactive ones only take part in the barriers below
+    const int nc = active ? n : N - 1;
     const bool has_gt = gt_depth != nullptr;
     const int ns = R.n_samples;
     const int nsurf = S - ns;
-    const float gt = has_gt ? gt_depth[n] : 0.f;
+    const float gt = has_gt ? gt_depth[nc] : 0.f;
     float gmax = gtmax_dev ? *gtmax_dev : gtmax_host;
     if (has_gt && !gtmax_dev && gtmax_host < 0.f) {         // batch maximum computed by every wave itself (small batches: one launch fewer)
         float mx = -NSK_INF;
         for (int i = lane; i < N; i += 64) mx = fmaxf(mx, gt_depth[i]);
         gmax = wave_max(mx);
     }
-    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
-    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    const float ox = rays_o[3 * nc], oy = rays_o[3 * nc + 1], oz = rays_o[3 * nc + 2];
+    const float dx = rays_d[3 * nc], dy = rays_d[3 * nc + 1], dz = rays_d[3 * nc + 2];
     float near = has_gt ? mul_rn(gt, 0.01f) : 0.01f;                        // :57,:63
     float far = add_rn(ray_box_far(R.bound, ox, oy, oz, dx, dy, dz), 0.01f);   // :69-73
     if (has_gt) {                                                           // :76
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(256) void k_sample(RParams R, int N, int S, const f
             float zu = lane < ns - 1 ? sh[wave][lane + 1] : z;
             float lo = lane == 0 ? z : mul_rn(0.5f, add_rn(z, zl));
             float up = lane == ns - 1 ? z : mul_rn(0.5f, add_rn(zu, z));
-            float u = (float)(hash_u32(R.seed, (uint32_t)n, (uint32_t)lane) >> 8) * (1.0f / 16777216.0f);
+            float u = (float)(hash_u32(R.seed, (uint32_t)nc, (uint32_t)lane) >> 8) * (1.0f / 16777216.0f);
             z = add_rn(lo, mul_rn(sub_rn(up, lo), u));
         }
         lds_fence();
@@ -170,7 +205,101 @@ __global__ __launch_bounds__(256) void k_sample(RParams R, int N, int S, const f
         lds_fence();
         z = sh2[wave][lane];
     }
-    if (lane < S) z_out[(size_t)n * S + lane] = z;
+    if (active && lane < S) z_out[(size_t)n * S + lane] = z;
+    if (!skey) return;                                                      // uniform over the launch
+    // ---- cell keys and ranks for the cell sort -----------------------------------------------------------------------------
+    if (blockIdx.x == 0 && threadIdx.x == 0) hist[-1] = 0;                 // the bump cursor of k_sort_scan (one int in front of the histogram)
+    for (int i = threadIdx.x; i < NSK_SAMPLE_TABLE; i += 64 * NSK_SAMPLE_RAYS) { tkey[i] = -1; tcnt[i] = 0; }
+    int cell = -1;
+    if (active && lane < S) {
+        const float px = add_rn(ox, mul_rn(dx, z)), py = add_rn(oy, mul_rn(dy, z)), pz = add_rn(oz, mul_rn(dz, z));   // = sample_finish
+        cell = cell_index(kX, kY, kZ, R.bound, px, py, pz) * 8;
+        // The coarser level read beside the key level (grid_middle under grid_fine / grid_color) does not nest in it: grid_sample's
+        // align_corners scaling puts its cell faces INSIDE key cells, so the samples of one key cell fall into up to 2 x 2 x 2 parent
+        // cells.  Three parity bits of the parent cell order them inside the key cell; without them they alternate at random and
+        // the parent level's scatter finds a new run at every other sample.
+        if (pX > 0) {
+            const int pc = cell_index(pX, pY, pZ, R.bound, px, py, pz);
+            const int ix = pc % pX, iy = (pc / pX) % pY, iz = pc / (pX * pY);
+            cell += (ix & 1) | ((iy & 1) << 1) | ((iz & 1) << 2);
+        }
+    }
+    // A ray crosses a cell once, so equal cells are consecutive lanes: one histogram add per run, made by its first lane.  The
+    // runs of the workgroup's rays are first merged in an LDS table (rays of one frame all start in the cells around the camera,
+    // and a thousand adds on one 64-byte line take 25 us: same-line atomics serialise at the memory side), then every
+    // distinct cell of the workgroup makes ONE returning add on the global histogram.
+    const int prev = __shfl_up(cell, 1);
+    const bool leader = active && lane < S && (lane == 0 || prev != cell);
+    const unsigned long long lead = __builtin_amdgcn_ballot_w64(leader);
+    const unsigned long long upto = (2ull << lane) - 1ull;                       // bits 0..lane
+    const int start = 63 - __builtin_clzll((lead & upto) | 1ull);
+    const unsigned long long above = lead & ~upto;
+    const int next = above ? __builtin_ctzll(above) : S;
+    __syncthreads();
+    int slot = 0, off = 0;
+    if (leader) {
+        unsigned h = ((unsigned)cell * 2654435761u) >> 21;                        // 11 bits
+        for (;;) {
+            const int old = atomicCAS(&tkey[h], -1, cell);
+            if (old == -1 || old == cell) break;
+            h = (h + 1) & (NSK_SAMPLE_TABLE - 1);
+        }
+        slot = (int)h;
+        off = atomicAdd(&tcnt[h], next - lane);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NSK_SAMPLE_TABLE; i += 64 * NSK_SAMPLE_RAYS)
+        if (tkey[i] >= 0) tbase[i] = atomicAdd(hist + hist_slot(tkey[i], ncell2), tcnt[i]);
+    __syncthreads();
+    int base = leader ? tbase[slot] + off : 0;
+    base = __shfl(base, start);
+    if (active && lane < S) { skey[(size_t)n * S + lane] = cell; srank[(size_t)n * S + lane] = base + (lane - start); }
+}
+
+// Offsets of the cell sort.  Each workgroup scans a chunk of 256 consecutive cells (2048 keys; one cell = 8 keys per thread) and
+// takes the chunk's place in the output with ONE returning add on a cursor: chunks land in arrival order (keys stay sorted
+// inside a chunk, which is all the tiles need), and no workgroup waits for another.  The histogram is cleared for the next step.
+__global__ __launch_bounds__(256) void k_sort_scan(int nkeys, int ncell2, int* __restrict__ hist, int* __restrict__ offs)
+{
+    __shared__ int wsum[4];
+    __shared__ int sbase;
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    int v[8], s = 0;
+    if (c0 < nkeys) {
+        const int4* src = reinterpret_cast<const int4*>(hist + hist_slot(c0, ncell2));
+        const int4 a = src[0], b = src[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    int incl = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) sbase = atomicAdd(hist - 1, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    __syncthreads();
+    int run = sbase + incl - s;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (c0 < nkeys) {
+        int o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { o[i] = run; run += v[i]; }
+        int4* dst = reinterpret_cast<int4*>(offs + c0);
+        dst[0] = make_int4(o[0], o[1], o[2], o[3]); dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+        if (s) { int4* h = reinterpret_cast<int4*>(hist + hist_slot(c0, ncell2)); h[0] = make_int4(0, 0, 0, 0); h[1] = make_int4(0, 0, 0, 0); }
+    }
+}
+
+__global__ void k_sort_place(int M, const int* __restrict__ skey, const int* __restrict__ srank, const int* __restrict__ offs,
+                             int* __restrict__ perm)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < M) perm[offs[skey[m]] + srank[m]] = m;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -512,6 +641,7 @@ __device__ __forceinline__ void coarse_forward(const f4* __restrict__ img, int l
 // ------------------------------------------------------------------------------------------------------
 struct DecArgs {
     const float* rays_o; const float* rays_d; const float* z; const float* pts;
+    const int* perm;          // cell-sorted sample order (k_sort_place): tile slot t -> sample perm[t]; nullptr = identity
     int M, S;
     float bound[6];
     GridD grid, grid_mid;
@@ -558,6 +688,23 @@ __device__ __forceinline__ void sample_finish(const DecArgs& A, const SampleRaw&
     pz = add_rn(R.o[2], mul_rn(R.d[2], R.z));
 }
 
+// sample handled by tile slot `slot` (clamped into [0, M)): the cell-sorted order when the launch has one, else the slot itself.
+// Per-sample state that only the decoders exchange (ReLU bits, saved block outputs) is indexed by SLOT, so it stays coalesced;
+// what the per-ray kernels read or write (z, occupancy, colour, g_raw) is indexed by SAMPLE.
+__device__ __forceinline__ int slot_sample(const DecArgs& A, int slot)
+{
+    const int s = min(slot, A.M - 1);
+    return A.perm ? A.perm[s] : s;
+}
+
+// Tile schedule shared by the decoder kernels: wave `wg` of `nw` takes blocks of 2^sh consecutive tiles, dealt round-robin over the
+// waves.  Single tiles (sh = 0) everywhere: dealing keeps the waves' loads equal (tiles in sparsely sampled space cost the scatter
+// one flush per sample, tiles inside a well-sampled cell one per tile; waves that owned a contiguous range of the former ran 100 us
+// behind), and blocks of 4 left up to 13 % of the forward's waves idle at 5000 rays.
+__device__ __forceinline__ int tile_shift(int, int) { return 0; }
+__device__ __forceinline__ int tile_of(int k, int wg, int nw, int sh) { return ((((k >> sh) * nw + wg)) << sh) + (k & ((1 << sh) - 1)); }
+__device__ __forceinline__ int tiles_per_wave(int ntasks, int nw, int sh) { return ((((ntasks + (1 << sh) - 1) >> sh) + nw - 1) / nw) << sh; }
+
 // The backward of a TRAINABLE decoder needs the block outputs h0..h4 as the X operands of its weight gradients.  The
 // forward stores them (one coalesced KiB per quad and tile) instead of the backward recomputing the MLP: 640 B per sample
 // of extra traffic against 277 MFMAs + two LDS image swaps per tile.
@@ -579,10 +726,16 @@ __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int n
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const float* imgf = reinterpret_cast<const float*>(smem);
     const int ntasks = (A.M + 15) >> 4;
-    for (int task = bid * NW + wave; task < ntasks; task += nb * NW) {
+    const int tsh = tile_shift(ntasks, nb * NW);
+    const int kmax = tiles_per_wave(ntasks, nb * NW, tsh);
+    for (int k = 0; k < kmax; ++k) {
+        const int task = tile_of(k, bid * NW + wave, nb * NW, tsh);
+        if (task >= ntasks) break;
         asm volatile("" ::: "memory");      // keep the LDS fragment reads inside the loop (LICM would hoist + spill them)
-        const int m = task * 16 + j;
-        const int mm = min(m, A.M - 1);
+        const int slot = task * 16 + j;
+        const bool valid = slot < A.M;
+        const int mm = slot_sample(A, slot);
+        const int m = mm;
         float px, py, pz, zz; int n;
         sample_point(A, mm, px, py, pz, zz, n);
         Tri T;
@@ -593,9 +746,9 @@ __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int n
             coarse_forward(smem, lane, C);
             float out[1];
             mlp_output<1>(imgf + CoarseFwdImg::P_WO, imgf + CoarseFwdImg::P_BO, g, C.h[4], out);
-            if (m < A.M) {
+            if (valid) {
                 if (g == 0) A.out[m] = out[0];
-                if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
+                if (A.masks) A.masks[(size_t)slot * 4 + g] = C.mask;
             }
             if (A.hsave) save_h(A.hsave, task, lane, C.h);
         } else {
@@ -614,12 +767,12 @@ __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int n
             mlp_forward<CQ>(smem, lane, C);
             float out[OD];
             mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);
-            if (m < A.M) {
+            if (valid) {
                 if (g == 0) {
                     if constexpr (OD == 4) *reinterpret_cast<f4*>(A.out + (size_t)m * 4) = (f4){out[0], out[1], out[2], out[OD - 1]};
                     else A.out[m] = out[0];
                 }
-                if (A.masks) A.masks[(size_t)m * 4 + g] = C.mask;
+                if (A.masks) A.masks[(size_t)slot * 4 + g] = C.mask;
             }
             if (A.hsave) save_h(A.hsave, task, lane, C.h);
         }
@@ -813,135 +966,79 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// scatter-add of a 16-sample tile's feature gradient into the grid gradient (voxel-major).  The tile's g_c is
-// transposed through per-wave LDS scratch so that each atomic wave-instruction adds two full 128-byte voxel lines
-// (the full-rate shape of global_atomic_add_f32, MI355X guide "Global float atomics"): lanes 0-31 own corners
-// 0-3 (dz = 0), lanes 32-63 corners 4-7 (dz = 1), of channel lane & 31.
-// Samples of a tile are consecutive along a ray (sorted by depth), so runs of samples share a cell: their
-// contributions are summed in registers and flushed once at the end of the run.  Cell ids come from the owning
-// lanes (v_readlane with a constant lane: lane jj holds sample jj's Tri), so run starts and ends are scalar flags
-// known without an LDS round trip, the accumulation is straight-line code, and the only branches are the uniform
-// ones around the flushes (measured: the branchy per-sample loop it replaces cost more than the atomics).
+// scatter-add of a 16-sample tile's feature gradient into the grid gradient (voxel-major).
+//
+// Samples of a tile that share a cell form a run (consecutive along a ray; whole tiles in cell-sorted order).  The sums
+//     out[run][corner][channel] = sum over the run's samples j of  w[j][corner] * g_c[j][channel]
+// are one small matrix product per pair of runs: A = the trilinear weights, masked by run, as a [2 runs x 8 corners] x [16 samples]
+// operand, B = g_c as [16 samples] x [16 channels] (two halves): eight v_mfma_f32_16x16x4_f32 per pair of runs.  The result tile
+// puts channel = lane & 15 and (run, four corners) = lane >> 4 into each lane, so every atomic wave-instruction adds four 64-byte
+// voxel segments.  Operands are transposed through a per-wave LDS scratch; there is no per-sample control flow, only the
+// uniform loop over run pairs (one or two passes in cell-sorted order), which keeps the code a few hundred instructions
+// (the scalar run-walking form it replaces unrolled to ~35 KB per decoder body, most of an instruction cache).
 // The optimiser mask is not consulted: Adam skips masked voxels and clears their gradient (k_adam_multi).
-// scratch: gct[16][36] floats + wts[16][8] floats  (2816 bytes)
+// scratch (floats): gT[32][20] | wT[8][20] | vT[16][8] (int) | rstart[16] (int)  = 944 floats
 // ------------------------------------------------------------------------------------------------------
+#define NSK_SCRATCH_FLOATS 944
 __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const f4 (&gc)[2], int lane, bool valid,
                                              float* __restrict__ scratch)
 {
     const int j = lane & 15, g = lane >> 4;
-    float* gct = scratch;                                   // [16][36]
-    float* wt = scratch + 16 * 36;                          // [16][8]
-    *reinterpret_cast<f4*>(gct + j * 36 + 4 * g) = valid ? gc[0] : (f4)(0.f);
-    *reinterpret_cast<f4*>(gct + j * 36 + 16 + 4 * g) = valid ? gc[1] : (f4)(0.f);
-    if (g == 0) {     // static indices only (a per-lane pick of two corners would index the register array dynamically)
-        *reinterpret_cast<f4*>(wt + j * 8) = valid ? (f4){T.w[0], T.w[1], T.w[2], T.w[3]} : (f4)(0.f);
-        *reinterpret_cast<f4*>(wt + j * 8 + 4) = valid ? (f4){T.w[4], T.w[5], T.w[6], T.w[7]} : (f4)(0.f);
+    float* gT = scratch;                                    // [32 channels][20]: column = sample
+    float* wT = scratch + 640;                              // [8 corners][20]
+    int* vT = reinterpret_cast<int*>(scratch + 800);        // [16 samples][8 corners] voxel indices
+    int* rstart = reinterpret_cast<int*>(scratch + 928);    // first sample of each run
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        gT[(4 * g + i) * 20 + j] = valid ? gc[0][i] : 0.f;
+        gT[(16 + 4 * g + i) * 20 + j] = valid ? gc[1][i] : 0.f;
     }
-    int cell[17];
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) cell[jj] = __builtin_amdgcn_readlane(T.vox[0], jj);
-    cell[16] = -1;
-    lds_fence();
-    const int ch = lane & 31;
-    const bool hf = lane >= 32;
-    float* const gch = G.g + ch;
-#ifdef NSK_EXPERIMENT
-    const bool dbg_noatomic = nsk_dbg_flags & 1;            // tools/exp_ts.py: keep the loop, drop the atomics
-#endif
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const float v = gct[jj * 36 + ch];
-        const f4 w4 = *reinterpret_cast<const f4*>(wt + jj * 8 + (hf ? 4 : 0));
-        const float keep = (jj > 0 && cell[jj] == cell[jj - 1]) ? 1.f : 0.f;        // scalar
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = fmaf(w4[c], v, acc[c] * keep);
-        if (cell[jj] != cell[jj + 1]) {                                             // uniform: the run ends here
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int lo = __builtin_amdgcn_readlane(T.vox[c], jj), hi = __builtin_amdgcn_readlane(T.vox[4 + c], jj);
-                const int vox = hf ? hi : lo;
-#ifdef NSK_EXPERIMENT
-                if (dbg_noatomic) { if (acc[c] == 12345.678f) gch[0] = 1.f; continue; }
-#endif
-                atomicAdd(gch + (size_t)vox * 32, acc[c]);
-            }
-        }
-    }
-    lds_fence();
-}
-
-// Face-sharing form.  Consecutive cells along a ray share a face, so when the ray steps into the neighbouring cell the
-// four accumulators of the shared face move to their new corner slots and only the four voxels left behind are
-// flushed: about half the atomic instructions of scatter_tile (a wave stalls once more than ~32 atomics are outstanding,
-// MI355X guide "float atomic add": with ~26 instead of ~48 per tile it no longer does).  The kind of step is decided
-// from scalars: the new cell id against the old cell's +x/+y/+z neighbour ids and vice versa (one v_readlane each).
-// scratch: gct[16][36] floats + wts[16][8] floats  (2816 bytes)
-__device__ __forceinline__ void scatter_tile_faces(const GridD& G, const Tri& T, const f4 (&gc)[2], int lane, bool valid,
-                                                   float* __restrict__ scratch)
-{
-    const int j = lane & 15, g = lane >> 4;
-    float* gct = scratch;                                   // [16][36]
-    float* wt = scratch + 16 * 36;                          // [16][8]
-    *reinterpret_cast<f4*>(gct + j * 36 + 4 * g) = valid ? gc[0] : (f4)(0.f);
-    *reinterpret_cast<f4*>(gct + j * 36 + 16 + 4 * g) = valid ? gc[1] : (f4)(0.f);
+    // run starts among the tile's 16 samples (lanes 0..15 carry them; every quarter of the wave holds the same Tri)
+    const int cell = T.vox[0];
+    const int prev = __shfl_up(cell, 1);
+    const bool st = j == 0 || cell != prev;
+    const unsigned mask16 = (unsigned)(__builtin_amdgcn_ballot_w64(st) & 0xffffull);
+    const int R = __builtin_popcount(mask16);
     if (g == 0) {
-        *reinterpret_cast<f4*>(wt + j * 8) = valid ? (f4){T.w[0], T.w[1], T.w[2], T.w[3]} : (f4)(0.f);
-        *reinterpret_cast<f4*>(wt + j * 8 + 4) = valid ? (f4){T.w[4], T.w[5], T.w[6], T.w[7]} : (f4)(0.f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wT[c * 20 + j] = valid ? T.w[c] : 0.f;
+        if (st) rstart[__builtin_popcount(mask16 & ((2u << j) - 1u)) - 1] = j;
+    } else if (g == 1) {
+        *reinterpret_cast<int4*>(vT + j * 8) = make_int4(T.vox[0], T.vox[1], T.vox[2], T.vox[3]);
+        *reinterpret_cast<int4*>(vT + j * 8 + 4) = make_int4(T.vox[4], T.vox[5], T.vox[6], T.vox[7]);
     }
     lds_fence();
-    const int ch = lane & 31;
-    const bool hf = lane >= 32;
-    float* const gch = G.g + ch;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int cur[4] = {0, 0, 0, 0};
-    int pc = -1, p1 = -1, p2 = -1, p4 = -1;                 // scalars: open cell and its +x / +y / +z neighbour voxels
-    auto flush = [&](int c) { atomicAdd(gch + (size_t)cur[c] * 32, acc[c]); };
-    float vv[16]; f4 ww[16];                                // every LDS read up front: none inside the branchy part
+    // operand view of the lane: row / column r16 = lane & 15, samples 4g .. 4g+3
+    const int r16 = j;
+    const f4 B0 = *reinterpret_cast<const f4*>(gT + r16 * 20 + 4 * g);
+    const f4 B1 = *reinterpret_cast<const f4*>(gT + (16 + r16) * 20 + 4 * g);
+    const f4 Wq = *reinterpret_cast<const f4*>(wT + (r16 & 7) * 20 + 4 * g);
+    int rj[4];
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) { vv[jj] = gct[jj * 36 + ch]; ww[jj] = *reinterpret_cast<const f4*>(wt + jj * 8 + (hf ? 4 : 0)); }
-    lds_fence();
+    for (int t = 0; t < 4; ++t) rj[t] = __builtin_popcount(mask16 & ((2u << (4 * g + t)) - 1u)) - 1;
+    float* const gcol = G.g + r16;
+    for (int p = 0; 2 * p < R; ++p) {                       // uniform: R is a wave-wide scalar
+        const int want = 2 * p + (r16 >> 3);
+        f4 d0 = (f4)(0.f), d1 = (f4)(0.f);
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const float v = vv[jj];
-        const f4 w4 = ww[jj];
-        const int nc = __builtin_amdgcn_readlane(T.vox[0], jj);
-        if (nc != pc) {                                     // uniform
-            const int n1 = __builtin_amdgcn_readlane(T.vox[1], jj), n2 = __builtin_amdgcn_readlane(T.vox[2], jj),
-                      n4 = __builtin_amdgcn_readlane(T.vox[4], jj);
-            if (pc >= 0) {
-                if (nc == p1) {                             // +x
-                    flush(0); flush(2); acc[0] = acc[1]; acc[2] = acc[3]; acc[1] = 0.f; acc[3] = 0.f;
-                } else if (n1 == pc) {                      // -x
-                    flush(1); flush(3); acc[1] = acc[0]; acc[3] = acc[2]; acc[0] = 0.f; acc[2] = 0.f;
-                } else if (nc == p2) {                      // +y
-                    flush(0); flush(1); acc[0] = acc[2]; acc[1] = acc[3]; acc[2] = 0.f; acc[3] = 0.f;
-                } else if (n2 == pc) {                      // -y
-                    flush(2); flush(3); acc[2] = acc[0]; acc[3] = acc[1]; acc[0] = 0.f; acc[1] = 0.f;
-                } else if (nc == p4) {                      // +z: the old dz = 1 face becomes the new dz = 0 face (other half wave)
-                    if (!hf) { flush(0); flush(1); flush(2); flush(3); }
+        for (int t = 0; t < 4; ++t) {
+            const float a = rj[t] == want ? Wq[t] : 0.f;
+            d0 = mfma4(a, B0[t], d0);
+            d1 = mfma4(a, B1[t], d1);
+        }
+        const int myrun = 2 * p + (g >> 1);                 // result rows 4g+i: run 2p + (g >> 1), corners 4 (g & 1) + i
+        if (myrun < R) {
+            const int js = rstart[myrun];
+            const int4 vx = *reinterpret_cast<const int4*>(vT + js * 8 + 4 * (g & 1));
+            const int v4[4] = {vx.x, vx.y, vx.z, vx.w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { const float o = __shfl_xor(acc[c], 32); acc[c] = hf ? 0.f : o; }
-                } else if (n4 == pc) {                      // -z
-                    if (hf) { flush(0); flush(1); flush(2); flush(3); }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { const float o = __shfl_xor(acc[c], 32); acc[c] = hf ? o : 0.f; }
-                } else {
-                    flush(0); flush(1); flush(2); flush(3);
-                    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
-                }
-            }
-            pc = nc; p1 = n1; p2 = n2; p4 = n4;
-            {
-                const int n3 = __builtin_amdgcn_readlane(T.vox[3], jj), n5 = __builtin_amdgcn_readlane(T.vox[5], jj),
-                          n6 = __builtin_amdgcn_readlane(T.vox[6], jj), n7 = __builtin_amdgcn_readlane(T.vox[7], jj);
-                cur[0] = hf ? n4 : nc; cur[1] = hf ? n5 : n1; cur[2] = hf ? n6 : n2; cur[3] = hf ? n7 : n3;
+            for (int i = 0; i < 4; ++i) {
+                float* dst = gcol + (size_t)v4[i] * 32;
+                atomicAdd(dst, d0[i]);
+                atomicAdd(dst + 16, d1[i]);
             }
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = fmaf(w4[c], v, acc[c]);
     }
-    flush(0); flush(1); flush(2); flush(3);
     lds_fence();
 }
 
@@ -1009,19 +1106,27 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     // The next tile's loads are issued at the top of this tile and forced to have landed before this tile's scatter: vmcnt
     // retires in order, so a load issued after the atomics would wait for all of them (the frozen roles spent more time
     // there than in their MFMA chain).
-    struct Staged { SampleRaw r; f4 gr; unsigned long long mask; } nx;
-    auto stage = [&](int task_, Staged& S_) {
-        const int mm_ = min(min(task_, ntasks - 1) * 16 + j, A.M - 1);
+    // With a cell-sorted launch the sample index itself is a load (perm): it is fetched two tiles ahead, the sample's data one.
+    struct Staged { SampleRaw r; f4 gr; unsigned long long mask; int mm; } nx;
+    auto slot_of = [&](int task_) { return min(min(task_, ntasks - 1) * 16 + j, A.M - 1); };
+    auto stage = [&](int task_, int mm_, Staged& S_) {
+        const int sl_ = slot_of(task_);
         sample_load(A, mm_, S_.r);
         S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm_ * 4);
-        S_.mask = A.masks[(size_t)mm_ * 4 + g];
+        S_.mask = A.masks[(size_t)sl_ * 4 + g];
+        S_.mm = mm_;
     };
-    stage(bid * 8 + wave, nx);
-    for (int task = bid * 8 + wave; task < ntasks; task += nb * 8) {
+    const int nw = nb * 8, wg = bid * 8 + wave;
+    const int tsh = tile_shift(ntasks, nw);
+    const int kmax = tiles_per_wave(ntasks, nw, tsh);
+    stage(tile_of(0, wg, nw, tsh), slot_sample(A, slot_of(tile_of(0, wg, nw, tsh))), nx);
+    int mm_next = slot_sample(A, slot_of(tile_of(1, wg, nw, tsh)));
+    for (int k = 0; k < kmax; ++k) {
+        const int task = tile_of(k, wg, nw, tsh);
+        if (task >= ntasks) break;
         asm volatile("" ::: "memory");      // keep the LDS fragment reads inside the loop (LICM would hoist + spill them)
-        const int m = task * 16 + j;
-        const bool valid = m < A.M;
-        const int mm = min(m, A.M - 1);
+        const bool valid = task * 16 + j < A.M;
+        const int mm = nx.mm;
         float px, py, pz;
         sample_finish(A, nx.r, px, py, pz);
         const float zz = A.pts ? 0.f : nx.r.z;
@@ -1036,7 +1141,8 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             else gout[0] = gr[3];
         }
         const unsigned long long mask = nx.mask;
-        stage(task + nb * 8, nx);
+        stage(tile_of(k + 1, wg, nw, tsh), mm_next, nx);
+        mm_next = slot_sample(A, slot_of(tile_of(k + 2, wg, nw, tsh)));
         f4 xcos[6];
         if constexpr (NEED_E) { f4 e[6]; embed<true>(Bm, g, px, py, pz, e, xcos); }
         f4 gh[2];                                                // g_h4 = Wo^T g_out
@@ -1092,7 +1198,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         }
         // opaque use: the staged registers must hold their data here, i.e. the loads retire before the first atomic below
         asm volatile("" : "+v"(nx.r.z), "+v"(nx.r.o[0]), "+v"(nx.r.o[1]), "+v"(nx.r.o[2]), "+v"(nx.r.d[0]), "+v"(nx.r.d[1]), "+v"(nx.r.d[2]),
-                          "+v"(nx.gr), "+v"(nx.mask));
+                          "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
         if constexpr (RAYS) {       // g_p through the embedding (g_e * cos(pB)) B^T and through the trilinear lookup
             float gp[3] = {0.f, 0.f, 0.f};
             if constexpr (NEED_E) {
@@ -1135,10 +1241,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             }
         }
         if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) {
-            // fewer atomics (face sharing) win once the launch is large enough to press on the chip-wide atomic rate; below that the
-            // straight-line form is quicker for the frozen roles (1000 rays: 119 vs 123 us, 10000 rays: 1085 vs 899 us)
-            if (A.flags & 256u) scatter_tile_faces(A.grid, T, gc, lane, valid, scratch);
-            else scatter_tile(A.grid, T, gc, lane, valid, scratch);
+            scatter_tile(A.grid, T, gc, lane, valid, scratch);
         }
     }
 }

@@ -190,7 +190,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     float* pn = smf + IMG_F;                        // shared panel
-    float* scratch = pn + wave * 832;               // per-wave scatter scratch: panel rows 0..63, idle between the last phase and phase OUT
+    float* scratch = pn + wave * 1056;              // per-wave scatter scratch (NSK_SCRATCH_FLOATS <= 1056): panel rows 0..63, idle between the last phase and phase OUT
     for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.bimg[i];
     __syncthreads();
     const f4* fimg = A.img;                         // !SAVED only: forward fragments from L2
@@ -207,23 +207,24 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     for (int k = 0; k < plan.nslots; ++k) acc[k] = (f4)(0.f);
 
     const int ntasks = (A.M + 15) >> 4;
-    const int per_iter = nb * 8;
-    const int iters = (ntasks + per_iter - 1) / per_iter;
+    const int iters = tiles_per_wave(ntasks, nb * 8, 0);
     const bool scat = (A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9);
     // Everything iteration it+1 reads from global memory (its samples, upstream gradient, gathered features, and the
     // forward image) is fetched at the end of iteration it BEFORE that iteration's scatter: vmcnt retires in order, so a
     // load issued after the atomics would wait for all of them (measured: 13k cycles at the top of an iteration).
     struct Staged { float px, py, pz, zz; int n; bool valid; f4 gr; f4 xc[CQ]; f4 h4[2]; unsigned long long mask; } nx;
-    auto stage_a = [&](int it_, Staged& S_) {          // issue the sample loads (no use, no wait)
-        const int task = (it_ * nb + bid) * 8 + wave;
-        const int m = task * 16 + j;
-        S_.valid = m < A.M;
-        const int mm = min(m, A.M - 1);
+    // single tiles dealt round-robin (tile_of with sh = 0): this role synchronises its 8 waves every iteration and carries nothing over
+    auto task_of = [&](int it_) { return tile_of(it_, bid * 8 + wave, nb * 8, 0); };
+    auto slot_of = [&](int it_) { return task_of(it_) * 16 + j; };
+    auto stage_a = [&](int it_, int mm, Staged& S_) {  // issue the sample loads (no use, no wait); mm = the slot's sample (perm, fetched an iteration earlier)
+        const int task = task_of(it_);
+        const int slot = task * 16 + j;
+        S_.valid = slot < A.M;
         sample_point(A, mm, S_.px, S_.py, S_.pz, S_.zz, S_.n);
         S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
         if constexpr (SAVED) {
             const int tk = min(task, ntasks - 1);
-            S_.mask = A.masks[(size_t)mm * 4 + g];
+            S_.mask = A.masks[(size_t)min(slot, A.M - 1) * 4 + g];
             S_.h4[0] = A.hsave[((size_t)tk * 10 + 8) * 64 + lane]; S_.h4[1] = A.hsave[((size_t)tk * 10 + 9) * 64 + lane];
         }
     };
@@ -237,7 +238,8 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             tri_gather(A.grid_mid, Tm, g, S_.xc[CQ - 2], S_.xc[CQ - 1]);
         }
     };
-    if (iters > 0) { stage_a(0, nx); stage_b(nx); }
+    int mm_next = 0;
+    if (iters > 0) { stage_a(0, slot_sample(A, slot_of(0)), nx); stage_b(nx); mm_next = slot_sample(A, slot_of(1)); }
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
         NSK_PH(0); NSK_PHI(0);
@@ -256,7 +258,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         ActC CC;
         f4 xcos[6];
         unsigned long long mask;
-        const int htask = min((it * nb + bid) * 8 + wave, ntasks - 1);          // this wave's tile in hsave
+        const int htask = min(task_of(it), ntasks - 1);                            // this wave's tile in hsave
         if constexpr (XYZ) {
 #pragma unroll
             for (int q = 0; q < CQ; ++q) C.xc[q] = nx.xc[q];
@@ -385,7 +387,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         NSK_PH(6); NSK_PHI(6);
         layer(std::integral_constant<int, 0>{});
         NSK_PH(7); NSK_PHI(7);
-        if (it + 1 < iters) stage_a(it + 1, nx);
+        if (it + 1 < iters) { stage_a(it + 1, mm_next, nx); mm_next = slot_sample(A, slot_of(it + 2)); }
         NSK_PH(8); NSK_PHI(8);
         float gp[3] = {0.f, 0.f, 0.f};
         asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));     // opaque: forces the recomputation below instead of keeping T / cos live
@@ -450,7 +452,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             stage_b(nx);
         }
         NSK_PH(17); NSK_PHI(17);
-        if (scat) scatter_tile_faces(A.grid, T, gc, lane, valid, scratch);
+        if (scat) scatter_tile(A.grid, T, gc, lane, valid, scratch);
         NSK_PH(10); NSK_PHI(10);
     }
     NSK_PH(11);

@@ -17,7 +17,7 @@ GROUP_DECODERS, GROUP_COARSE, GROUP_MIDDLE, GROUP_FINE, GROUP_COLOR, GROUP_CAMER
 # every symbol include/nsk.h declares
 SYMBOLS = (
     "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
-    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap", "nsk_sample_pixels", "nsk_gather_pixels", "nsk_rays_from_camera", "nsk_pose_step",
+    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_set_sort_mode", "nsk_set_tuning", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap", "nsk_sample_pixels", "nsk_gather_pixels", "nsk_rays_from_camera", "nsk_pose_step",
     "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
@@ -33,10 +33,8 @@ class NskError(RuntimeError):
 
 def build(force=False):
     """compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)"""
-    src = [os.path.join(_HERE, "csrc", f) for f in ("nsk.hip", "nsk_device.h", "nsk_layout.h")]
-    src.append(os.path.join(_HERE, "..", "include", "nsk.h"))
-    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "all"])
+    # staleness is make's business: csrc/Makefile lists every source and header of the library
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")] + (["-B"] if force else []) + ["all"])
     return _LIB_PATH
 
 
@@ -144,6 +142,13 @@ class Context:
 
     def set_matmul_mode(self, mode):
         _chk(lib().nsk_set_matmul_mode(self.h, int(mode)))
+
+    def set_sort_mode(self, mode):
+        """-1 automatic, 0 ray order, 1 cell-sorted (include/nsk.h)"""
+        _chk(lib().nsk_set_sort_mode(self.h, int(mode)))
+
+    def set_tuning(self, key, value):
+        _chk(lib().nsk_set_tuning(self.h, key.encode(), int(value)))
 
     def sync(self):
         _chk(lib().nsk_sync(self.h))
@@ -425,12 +430,20 @@ class Context:
     def zero_grads(self):
         _chk(lib().nsk_zero_grads(self.h))
 
+    @_ordered
     def grad_slab(self):
-        """the contiguous gradient slab as a torch tensor aliasing context memory (for torch.distributed all-reduce)"""
+        """the contiguous gradient slab as a torch tensor aliasing context memory (for torch.distributed all-reduce).
+        nsk_grad_slab launches the pending decoder-gradient reduction on the context's stream, so the call is stream-ordered
+        like every other launching method: the caller's stream waits for it before the exchange reads the slab.  The wrapping
+        tensor is cached per (pointer, size): no per-step host work beyond the C call."""
         import torch
         p, n = C.c_void_p(), C.c_size_t()
         _chk(lib().nsk_grad_slab(self.h, C.byref(p), C.byref(n)))
-        return torch.as_tensor(_CudaArray(p.value, n.value), device="cuda:%d" % self.device)
+        key = (p.value, n.value)
+        if getattr(self, "_slab_key", None) != key:
+            self._slab_t = torch.as_tensor(_CudaArray(p.value, n.value), device="cuda:%d" % self.device)
+            self._slab_key = key
+        return self._slab_t
 
     def profile_begin(self):
         _chk(lib().nsk_profile_begin(self.h))

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: one mapping iteration (render forward + Mapper loss + backward + [all-reduce] +
-Adam) per step, on BASELINE.json configs[1]: config/nice_slam.yaml grids (Replica-room0-class bound, 3-level
-grid), 1000 rays x 48 samples per GPU, colour stage.  Prints ONE JSON line (rank 0).
+"""Benchmark of the hot path: one mapping iteration (cell sort + render forward + Mapper loss + backward + [all-reduce] +
+Adam) per step.  Prints ONE JSON line (rank 0).
+
+Headline workload (N = 1): BASELINE.json configs[2], the largest single-GPU configuration -- a ScanNet-scene0000_00-class
+room (bound and intrinsics declared in tests/scenes.py: the reference has no such config), 5000 rays x 48 samples, colour-stage
+iteration (renders the middle + fine + colour decoders, i.e. a superset of the fine stage; the fine-stage iteration of the same
+workload, configs[1] (config/nice_slam.yaml, 1000 rays) and a configs[3] shard (1250 rays) are reported under "extras").
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rays shard across ranks with no data-path exchange except ONE all-reduce (RCCL, sum, fp32) of the gradient
-slab per step; per-GPU work is fixed, so scaling is "weak".
+Rays shard across ranks with no data-path exchange except ONE all-reduce (RCCL, sum, fp32) of the gradient slab per step
+(SURVEY.md 8e); per-GPU work is fixed, so scaling is "weak".
 """
 import argparse
 import json
@@ -26,54 +30,243 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0              # same guide, HBM3E peak
+PMC_FILE = "r02_pmc_hbm.json"      # profiles/: FETCH_SIZE / WRITE_SIZE passes of the default command (tools/profile_round.sh)
 
-# algorithmic MACs per sample of each kernel (DESIGN.md "Kernels")
+# algorithmic MACs per sample of each decoder role (DESIGN.md "Kernels")
 MAC = {
-    "decode_fwd_coarse": 6176, "decode_fwd_middle": 15479, "decode_fwd_fine": 20599, "decode_fwd_color": 15575,
-    "decode_bwd_coarse": 6176, "decode_bwd_middle": 9248, "decode_bwd_fine": 9248, "decode_bwd_color": 9344,
-    # trainable: input gradients + embedding-gradient products + weight gradients (block outputs come from the forward, which
-    # saved them: no recompute; the fine decoder still recomputes its forward)
-    "decode_bwd_coarse_train": 6176 * 2, "decode_bwd_middle_train": 9248 + 5952 + 15479,
-    "decode_bwd_fine_train": 20599 + 9248 + 5952 + 20599, "decode_bwd_color_train": 9344 + 5952 + 15575,
+    "fwd_coarse": 6176, "fwd_middle": 15479, "fwd_fine": 20599, "fwd_color": 15575,
+    "bwd_coarse": 6176, "bwd_middle": 9248, "bwd_fine": 9248, "bwd_color": 9344,
+    # trainable: input gradients + embedding-gradient products + weight gradients (block outputs are saved by the forward)
+    "bwd_color_train": 9344 + 5952 + 15575,
 }
-# algorithmic HBM bytes per sample of each kernel: 8 corners x 32 ch x 4 B per level read, 2x that per level
-# scattered (read-modify-write), plus per-sample intermediates
+# algorithmic HBM bytes per sample: 8 corners x 32 ch x 4 B per level read, 2x that per level scattered (read-modify-write),
+# plus per-sample intermediates (z, outputs, ReLU bits, saved block outputs of the trainable decoder)
 BYTES = {
-    "decode_fwd_coarse": 1024 + 8, "decode_fwd_middle": 1024 + 8, "decode_fwd_fine": 2048 + 8, "decode_fwd_color": 1024 + 20,
-    "decode_bwd_coarse": 2048 + 20, "decode_bwd_middle": 2048 + 52, "decode_bwd_fine": 2048 + 52, "decode_bwd_color": 2048 + 52,
-    "decode_bwd_coarse_train": 3072 + 20 + 640, "decode_bwd_middle_train": 3072 + 20 + 640, "decode_bwd_fine_train": 4096 + 20,
-    "decode_bwd_color_train": 3072 + 20 + 640,          # + the 160 saved block outputs read back
+    "fwd_coarse": 1024 + 8, "fwd_middle": 1024 + 8, "fwd_fine": 2048 + 8, "fwd_color": 1024 + 20 + 640,
+    "bwd_coarse": 2048 + 20, "bwd_middle": 2048 + 52, "bwd_fine": 2048 + 52, "bwd_color": 2048 + 52,
+    "bwd_color_train": 3072 + 20 + 640,
 }
+STAGE_DECODERS = {"coarse": ["coarse"], "middle": ["middle"], "fine": ["middle", "fine"], "color": ["middle", "fine", "color"]}
+# mapping.stage.<stage> learning rates of config/nice_slam.yaml:71-95 (groups: decoders, coarse, middle, fine, color, camera)
+STAGE_LR = {"coarse": [0.0, 0.001, 0.0, 0.0, 0.0, 0.0], "middle": [0.0, 0.0, 0.1, 0.0, 0.0, 0.0],
+            "fine": [0.0, 0.0, 0.005, 0.005, 0.0, 0.0], "color": [0.005, 0.0, 0.005, 0.005, 0.005, 0.0]}
 
 
-def cpu_baseline(sc, rays_list, lr, w_color, seconds=12.0):
-    """the oracle (a port of the reference's path, oracle/nso.c) timed on this host: same step, same inputs"""
+def workloads():
+    import scenes
+    return {
+        "K3": dict(bound=scenes.K3_BOUND, cam=scenes.CAM_SCANNET, rays=5000,
+                   name="configs[2]: ScanNet scene0000_00-class room (bound [[0,8.6],[0,8.9],[-0.3,3.3]], 640x480 camera; declared in the "
+                        "harness, the reference holds no such config), grids of src/main.cpp:34-75 for that bound"),
+        "K2": dict(bound=scenes.REF_BOUND, cam=scenes.CAM_NICE_SLAM, rays=1000,
+                   name="configs[1]: config/nice_slam.yaml grids (bound of src/main.cpp:33, Replica-room0-class), 1200x680 camera"),
+        "K4": dict(bound=scenes.K4_BOUND, cam=scenes.CAM_NICE_SLAM, rays=1250,
+                   name="configs[3] shard: Replica office0-class room, 10000 rays / 8 GPUs = 1250 rays per GPU"),
+    }
+
+
+def alg_counts(stage, trainable_color):
+    """(MAC, bytes) per sample of the forward and backward launches of a stage"""
+    decs = STAGE_DECODERS[stage]
+    fm = sum(MAC["fwd_" + d] for d in decs)
+    fb = sum(BYTES["fwd_" + d] for d in decs)
+    bm = sum(MAC["bwd_color_train" if (d == "color" and trainable_color) else "bwd_" + d] for d in decs)
+    bb = sum(BYTES["bwd_color_train" if (d == "color" and trainable_color) else "bwd_" + d] for d in decs)
+    return fm, fb, bm, bb
+
+
+def cpu_threads():
+    """host threads a CPU baseline may use: the process's CPU share (cgroup quota if any, else its affinity mask), capped at the
+    GPU box's documented per-GPU share of 16 cores (NSK_CPU_THREADS overrides) -- the box shows 256 logical CPUs, and 256
+    threads on these small ops ran the ATen step 600x slower than 16 do"""
+    try:
+        n = max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("NSK_CPU_THREADS", "16"))))
+
+
+def cpu_baseline_c(sc, rays_list, stage, lr, w_color, seconds):
+    """the oracle (a plain-C port of the reference's path, oracle/nso.c, OpenMP over rays) timed on this host: same step, same inputs"""
     from oracle.nso import Oracle
     o = Oracle("f32")
+    o.lib.nso_set_num_threads(cpu_threads())
     threads = int(o.lib.nso_num_threads())
     grids = {k: v.copy() for k, v in sc["grids"].items()}
     decs = {k: v.copy() for k, v in sc["decoders"].items()}
-    mom = {k: (np.zeros_like(grids[k]), np.zeros_like(grids[k])) for k in ("middle", "fine", "color")}
+    levels = [k for k in STAGE_DECODERS[stage]]
+    mom = {k: (np.zeros_like(grids[k]), np.zeros_like(grids[k])) for k in levels}
     dm, dv = np.zeros_like(decs["color"]), np.zeros_like(decs["color"])
     op = o.opts(sc["bound"])
     n_rays, steps, t0 = 0, 0, time.perf_counter()
     while True:
         r = rays_list[steps % len(rays_list)]
-        fw = o.render_forward(op, grids, decs, "color", r["rays_o"], r["rays_d"], r["gt_depth"])
-        _, g_d, g_c = o.loss_map(fw["depth"], fw["rgb"], r["gt_depth"], r["gt_color"], w_color, True)
-        bw = o.render_backward(op, grids, decs, "color", r["rays_o"], r["rays_d"], r["gt_depth"], -1.0, g_c, g_d, None,
-                               want_rays=False)
+        fw = o.render_forward(op, grids, decs, stage, r["rays_o"], r["rays_d"], r["gt_depth"])
+        _, g_d, g_c = o.loss_map(fw["depth"], fw["rgb"], r["gt_depth"], r["gt_color"], w_color, stage == "color")
+        bw = o.render_backward(op, grids, decs, stage, r["rays_o"], r["rays_d"], r["gt_depth"], -1.0, g_c, g_d, None, want_rays=False)
         steps += 1
         for k in mom:
             o.adam_step(grids[k], bw["g_grids"][k], mom[k][0], mom[k][1], lr[2], steps)
-        o.adam_step(decs["color"], bw["g_decoders"]["color"], dm, dv, lr[0], steps)
+        if stage == "color":
+            o.adam_step(decs["color"], bw["g_decoders"]["color"], dm, dv, lr[0], steps)
         n_rays += r["rays_o"].shape[0]
         if time.perf_counter() - t0 > seconds or steps >= 50:
             break
     dt = time.perf_counter() - t0
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port", "impl": "oracle/nso.c (plain C, analytic backward, OpenMP over rays)",
+            "sample": "%d full mapping steps of %d rays x 48 samples (%s stage, same scene), %.1f s" % (steps, rays_list[0]["rays_o"].shape[0], stage, dt),
+            "ms_per_step": 1e3 * dt / steps}
+
+
+def cpu_baseline_aten(sc, rays_list, stage, lr, w_color, seconds):
+    """the reference's execution style on the host: the ATen op sequence the reference calls (F.grid_sample, F.linear, sort, cumprod,
+    autograd, torch.optim.Adam -- oracle/torch_ref.py restates src/Renderer.cpp, src/models/*.cpp, utils.h, src/Mapper.cpp:330-446 op for
+    op, SURVEY.md section 0.3 semantics) with torch.set_num_threads(all host cores of this process)"""
+    from oracle import torch_ref as T
+    threads = cpu_threads()
+    torch.set_num_threads(threads)
+    bound = torch.tensor(np.asarray(sc["bound"], np.float32))
+    levels = STAGE_DECODERS[stage]
+    grids = {k: torch.tensor(v[None].copy()) for k, v in sc["grids"].items()}
+    decs = {k: torch.tensor(v.copy()) for k, v in sc["decoders"].items()}
+    groups = []
+    for gi, k in ((2, "middle"), (3, "fine"), (4, "color"), (1, "coarse")):
+        if k in levels:
+            grids[k].requires_grad_(True)
+            groups.append({"params": [grids[k]], "lr": lr[gi]})
+    if stage == "color":
+        decs["color"].requires_grad_(True)
+        groups.append({"params": [decs["color"]], "lr": lr[0]})
+    opt = torch.optim.Adam(groups)                                              # src/Mapper.cpp:330
+    tens = [{k: torch.tensor(r[k]) for k in ("rays_o", "rays_d", "gt_depth", "gt_color")} for r in rays_list]
+
+    def step(i):
+        r = tens[i % len(tens)]
+        opt.zero_grad()
+        rgb, depth, var, w = T.render_batch_ray(grids, decs, r["rays_d"], r["rays_o"], stage, r["gt_depth"], bound)
+        loss = T.loss_map(depth, rgb, r["gt_depth"], r["gt_color"], w_color, stage == "color")
+        loss.backward()
+        opt.step()
+        return r["rays_o"].shape[0]
+
+    step(0)                                                                     # warm-up (thread pool, allocator)
+    n_rays, steps, t0 = 0, 0, time.perf_counter()
+    while True:
+        n_rays += step(steps + 1)
+        steps += 1
+        if time.perf_counter() - t0 > seconds or steps >= 50:
+            break
+    dt = time.perf_counter() - t0
     return {"value": n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": "%d full mapping steps of %d rays x 48 samples (colour stage, same scene), %.1f s, OpenMP over rays"
-                      % (steps, rays_list[0]["rays_o"].shape[0], dt), "ms_per_step": 1e3 * dt / steps}
+            "impl": "ATen-CPU op sequence of the reference with autograd + torch.optim.Adam (oracle/torch_ref.py), torch %s, %d threads" % (torch.__version__, threads),
+            "sample": "%d full mapping steps of %d rays x 48 samples (%s stage, same scene and rays as the GPU run), %.1f s after 1 warm-up step"
+                      % (steps, rays_list[0]["rays_o"].shape[0], stage, dt),
+            "ms_per_step": 1e3 * dt / steps}
+
+
+def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, keep=False):
+    """time `steps` mapping iterations of workload `wl` at `N` rays per GPU; returns dict(dt, prof, loss, scene, pool)"""
+    import nice_slam_cpp_amd as pkg
+    import nice_slam_cpp_amd.dist as nd
+    import scenes
+    dev = torch.device("cuda", local)
+    cam = wl["cam"]
+    sc = scenes.make_scene(42, scenes.grid_shapes_for(wl["bound"]), bound=wl["bound"])     # grid shapes + init of src/main.cpp:33-78
+    pool = [scenes.make_rays(1234 + 17 * i + 1000 * rank, N, sc["bound"], n_frames=5, **cam) for i in range(8)]
+    ctx = pkg.Context(local)
+    ctx.set_render_opts()                                        # 32 + 16 samples (src/Renderer.cpp:9-10)
+    ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
+    train_color = stage == "color"
+    ctx.decoder_set_trainable("color", train_color)              # fix_fine: True, fix_color: False (nice_slam.yaml:51-52)
+    lr = STAGE_LR[stage]
+    w_color = 0.5                                                # src/Mapper.cpp:33 reads tracking.w_color_loss (D20)
+    cu = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev).contiguous()
+    batches = []
+    for r in pool:
+        gd = cu(r["gt_depth"])
+        gmax = nd.global_depth_max(gd)                           # batch-global max(gt_depth) (Renderer.cpp:76,93)
+        batches.append((cu(r["rays_o"]), cu(r["rays_d"]), gd, cu(r["gt_color"]), gmax))
+    loss = torch.zeros(1, device=dev)
+    flags = pkg.nsk.GRAD_GRIDS | (pkg.nsk.GRAD_DECODERS if train_color else 0)
+
+    with torch.cuda.stream(ctx.tstream):
+        slab = ctx.grad_slab() if world > 1 else None            # wraps context memory once; nsk_grad_slab is still called per step below
+
+        def step(i):
+            ro, rd, gd, gc, gmax = batches[i % len(batches)]
+            ctx.map_step(stage, ro, rd, gd, gc, gmax, w_color, stage == "color", flags=flags, loss=loss)
+            if world > 1:                                        # the one exchange of the path; grad_slab() completes the
+                nd.allreduce_grads(ctx.grad_slab())              # step's pending gradient reductions before it is read
+            ctx.adam_step(lr)
+
+        eager_step = step
+        if graph and world == 1:                                 # one graph per batch of the pool, replayed instead of re-issued
+            step(0)                                              # sizes the workspaces
+            gids = []
+            for b in range(len(batches)):
+                ctx.graph_begin(); step(b); gids.append(ctx.graph_end())
+
+            def step(i):                                         # noqa: F811
+                ctx.graph_launch(gids[i % len(gids)])
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        # per-kernel durations: HIP events recorded on the context's stream around every launch (same steps again)
+        ctx.profile_begin()
+        for i in range(steps):
+            eager_step(warmup + i)
+        prof = ctx.profile_end()
+        final_loss = float(loss)
+    out = dict(dt=dt, prof=prof, loss=final_loss, sc=sc, pool=pool, lr=lr, w_color=w_color, slab_floats=int(ctx.grad_slab().numel()))
+    ctx.close()
+    return out
+
+
+def summarize(res, stage, N, steps, world):
+    S = 48
+    M = N * S
+    prof = res["prof"]
+    per_kernel = {k: {"launches": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in prof.items()}
+    fm, fb, bm, bb = alg_counts(stage, stage == "color")
+    fwd_name = "decode_fwd_multi" if "decode_fwd_multi" in prof else next(k for k in prof if k.startswith("decode_fwd"))
+    bwd_name = "decode_bwd_multi" if "decode_bwd_multi" in prof else next(k for k in prof if k.startswith("decode_bwd"))
+    alg = {fwd_name: (fm, fb), bwd_name: (bm, bb)}
+    dom = max(alg, key=lambda k: prof[k][1])
+    dom_s = prof[dom][1] / prof[dom][0] * 1e-3
+    flops = 2.0 * alg[dom][0] * M
+    roof = {"bound": "mfma", "kernel": dom, "achieved": flops / dom_s / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "avg_launch_us": dom_s * 1e6, "alg_flops_per_launch": flops,
+            "alg_bytes_per_launch": alg[dom][1] * M, "hbm_frac_same_kernel": alg[dom][1] * M / dom_s / 1e9 / PEAK_HBM_GBS}
+    step_s = res["dt"] / steps
+    nparam = sum(res["sc"]["grids"][k].size for k in STAGE_DECODERS[stage])
+    step_bytes = float(fb + bb) * M + 28.0 * nparam
+    step_flops = 2.0 * (fm + bm) * M + 1000.0 * M                       # + sampling / compositing
+    return {"value": world * N / step_s, "ms_per_step": 1e3 * step_s, "roofline": roof,
+            "step_rooflines": {"alg_bytes_per_step": step_bytes, "hbm_frac": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
+                               "alg_flops_per_step": step_flops, "fp32_frac": step_flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+            "kernels": per_kernel, "final_loss": res["loss"]}
 
 
 def main():
@@ -81,11 +274,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rays", type=int, default=1000, help="rays per GPU per step (config/nice_slam.yaml mapping.pixels)")
+    ap.add_argument("--workload", default="K3", choices=["K3", "K2", "K4"])
+    ap.add_argument("--rays", type=int, default=0, help="rays per GPU per step (0 = the workload's own count)")
     ap.add_argument("--stage", default="color")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the K2 / fine-stage / K4-shard lines under 'extras'")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step as a captured hipGraph (single GPU)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of each CPU baseline's timed sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,120 +301,54 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    import nice_slam_cpp_amd as pkg
-    import scenes
-
-    N = args.rays
-    sc = scenes.make_scene(42)                                   # reference grid shapes + init (src/main.cpp:33-78)
-    pool = [scenes.make_rays(1234 + 17 * i + 1000 * rank, N, sc["bound"], n_frames=5) for i in range(8)]
-    ctx = pkg.Context(local)
-    ctx.set_render_opts()                                        # 32 + 16 samples (src/Renderer.cpp:9-10)
-    ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
-    ctx.decoder_set_trainable("color", True)                     # fix_fine: True, fix_color: False (nice_slam.yaml:51-52)
-    lr = [0.005, 0.0, 0.005, 0.005, 0.005, 0.0]                  # mapping.stage.color (nice_slam.yaml:90-95), lr_factor 1
-    w_color = 0.5                                                # src/Mapper.cpp:33 reads tracking.w_color_loss (D20)
-    dev = torch.device("cuda", local)
-    cu = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev).contiguous()
-    batches = []
-    import nice_slam_cpp_amd.dist as nd
-    for r in pool:
-        gd = cu(r["gt_depth"])
-        gmax = nd.global_depth_max(gd)                           # batch-global max(gt_depth) (Renderer.cpp:76,93)
-        batches.append((cu(r["rays_o"]), cu(r["rays_d"]), gd, cu(r["gt_color"]), gmax))
-    loss = torch.zeros(1, device=dev)
-    flags = pkg.nsk.GRAD_GRIDS | pkg.nsk.GRAD_DECODERS
-
-    with torch.cuda.stream(ctx.tstream):
-        def step(i):
-            ro, rd, gd, gc, gmax = batches[i % len(batches)]
-            ctx.map_step(args.stage, ro, rd, gd, gc, gmax, w_color, True, flags=flags, loss=loss)
-            if world > 1:                                        # the one exchange of the path; grad_slab() completes the
-                nd.allreduce_grads(ctx.grad_slab())              # step's pending gradient reductions before it is read
-            ctx.adam_step(lr)
-
-        if args.graph and world == 1:                           # one graph per batch of the pool, replayed instead of re-issued
-            step(0)                                              # sizes the workspaces
-            gids = []
-            for b in range(len(batches)):
-                ctx.graph_begin(); step(b); gids.append(ctx.graph_end())
-            eager_step = step
-
-            def step(i):                                         # noqa: F811
-                ctx.graph_launch(gids[i % len(gids)])
-        for i in range(args.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t)
-        # per-kernel durations: HIP events recorded on the context's stream around every launch (same steps again)
-        ctx.profile_begin()
-        for i in range(args.steps):
-            (eager_step if args.graph and world == 1 else step)(args.warmup + i)      # events are recorded around eager launches
-        prof = ctx.profile_end()
-        final_loss = float(loss)
-
+    W = workloads()
+    wl = W[args.workload]
+    N = args.rays or wl["rays"]
+    res = run_workload(wl, args.stage, N, args.steps, args.warmup, local, rank, world, dist, graph=args.graph)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    S = 48
-    M = N * S
-    per_kernel = {k: {"launches": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in prof.items()}
-    # merged launches: all decoders of the stage run as workgroup roles of one kernel
-    MAC["decode_fwd_multi"] = MAC["decode_fwd_middle"] + MAC["decode_fwd_fine"] + (MAC["decode_fwd_color"] if args.stage == "color" else 0)
-    BYTES["decode_fwd_multi"] = BYTES["decode_fwd_middle"] + BYTES["decode_fwd_fine"] + (BYTES["decode_fwd_color"] + 640 if args.stage == "color" else 0)
-    MAC["decode_bwd_multi"] = MAC["decode_bwd_middle"] + MAC["decode_bwd_fine"] + (MAC["decode_bwd_color_train"] if args.stage == "color" else 0)
-    BYTES["decode_bwd_multi"] = BYTES["decode_bwd_middle"] + BYTES["decode_bwd_fine"] + (BYTES["decode_bwd_color_train"] if args.stage == "color" else 0)
-    dom = max((k for k in prof if k.startswith("decode")), key=lambda k: prof[k][1])
-    dom_s = prof[dom][1] / prof[dom][0] * 1e-3
-    flops = 2.0 * MAC[dom] * M
-    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    # (profiles/r01f_pmc_hbm.json, tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the
-    # MI355X guide prescribes for gfx950).  Only valid for the default 1000-ray workload the passes were run on.
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01f_pmc_hbm.json")
-    if os.path.exists(pmc_path) and N == 1000 and args.stage == "color":
+    head = summarize(res, args.stage, N, args.steps, world)
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same (default) command:
+    # FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950
+    pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
+    if os.path.exists(pmc_path) and args.workload == "K3" and N == W["K3"]["rays"] and args.stage == "color":
         pmc = json.load(open(pmc_path))
-        prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "k_decode_fwd_multi_bf16"}.get(dom)
+        prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "void k_decode_fwd_multi_bf16"}.get(head["roofline"]["kernel"])
         get = lambda c: next((v for k, v in pmc.items() if prefix and k.startswith(prefix) and k.endswith("|" + c)), None)
         if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
-            traffic = (2.0 * get("FETCH_SIZE") + get("WRITE_SIZE")) * 1024.0
-    roof = {"bound": "mfma", "kernel": dom, "achieved": flops / dom_s / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-            "avg_launch_us": dom_s * 1e6, "alg_flops_per_launch": flops,
-            "alg_bytes_per_launch": BYTES[dom] * M, "hbm_frac_same_kernel": BYTES[dom] * M / dom_s / 1e9 / PEAK_HBM_GBS}
-    step_bytes = (9221.0 + 1280.0) * M + 28.0 * sum(sc["grids"][k].size for k in ("middle", "fine", "color"))   # + saved block outputs, written and read
-    step_flops = 2.0 * (MAC["decode_fwd_multi"] + MAC["decode_bwd_multi"]) * M + 1000.0 * M                    # + sampling / compositing
+            head["roofline"]["traffic"] = (2.0 * get("FETCH_SIZE") + get("WRITE_SIZE")) * 1024.0
     out = {
         "metric": "mapping rays/sec (and ms/iter) on CoFusion room1 at 1/2/4/8 MI355X",
-        "value": world * N * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": head["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: config/nice_slam.yaml grids (bound of src/main.cpp:33, 3-level grid + colour), "
-                               "%d rays x 48 samples per GPU, colour-stage mapping iteration "
-                               "(forward + L1 depth/colour loss + backward to middle/fine/colour grids and colour decoder + Adam)" % N,
-                   "rays_per_gpu": N, "samples_per_ray": S, "stage": args.stage,
-                   "matmul": "forward: fp32 operands as 3 bf16 pieces, 6 bf16 MFMAs per product (fp32-accurate); backward: fp32 MFMA", "parallelism": "rays sharded x%d, 1 all-reduce/step" % world},
-        "roofline": roof,
-        "step_rooflines": {"alg_bytes_per_step": step_bytes, "hbm_frac": step_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS,
-                           "alg_flops_per_step": step_flops, "fp32_frac": step_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
-        "kernels": per_kernel, "final_loss": final_loss,
+        "config": {"workload": "%s; %d rays x 48 samples per GPU, %s-stage mapping iteration (cell sort of the samples + forward + L1 depth/colour loss + "
+                               "backward to the %s grids%s + Adam)" % (wl["name"], N, args.stage, "/".join(STAGE_DECODERS[args.stage]),
+                                                                     " and the colour decoder" if args.stage == "color" else ""),
+                   "id": args.workload, "rays_per_gpu": N, "samples_per_ray": 48, "stage": args.stage,
+                   "grid_shapes": {k: list(v.shape) for k, v in res["sc"]["grids"].items()},
+                   "matmul": "fp32 operands as bf16 pieces on the matrix cores with fp32 accumulation (3 pieces = fp32-accurate: forward, frozen-decoder "
+                             "backward chains), fp32 MFMA for the trainable decoder's chain, its weight-gradient panels and the grid-gradient scatter",
+                   "parallelism": "rays sharded x%d, 1 all-reduce/step of %d floats" % (world, res["slab_floats"])},
+        "roofline": head["roofline"], "step_rooflines": head["step_rooflines"], "kernels": head["kernels"], "final_loss": head["final_loss"],
     }
+    if world == 1 and not args.no_extras:
+        extras = {}
+        for name, wname, stage, n, k in (("K3_fine_stage", "K3", "fine", W["K3"]["rays"], 50), ("K2_color", "K2", "color", W["K2"]["rays"], 100),
+                                         ("K4_shard_color", "K4", "color", W["K4"]["rays"], 100)):
+            if wname == args.workload and stage == args.stage and n == N:
+                continue
+            r = run_workload(W[wname], stage, n, k, 10, local, rank, world, None)
+            s = summarize(r, stage, n, k, 1)
+            extras[name] = {"workload": W[wname]["name"], "stage": stage, "rays": n, "steps": k, "value": s["value"], "unit": "rays/s",
+                            "ms_per_step": s["ms_per_step"], "roofline_frac": s["roofline"]["frac"], "roofline_kernel": s["roofline"]["kernel"],
+                            "kernels_avg_us": {kk: round(v["avg_us"], 2) for kk, v in s["kernels"].items()}}
+        out["extras"] = extras
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(sc, pool, lr, w_color, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline_aten(res["sc"], res["pool"], args.stage, res["lr"], res["w_color"], args.cpu_seconds)
+        out["cpu_baseline_c_port"] = cpu_baseline_c(res["sc"], res["pool"], args.stage, res["lr"], res["w_color"], args.cpu_seconds)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -795,6 +795,17 @@ NSO_API int nso_inside_filter(const real* bound, int N, const real* rays_o, cons
     return c;
 }
 
+/* bound the OpenMP team (bench.py: the GPU box shows 256 logical CPUs to a process whose share is 16; every thread of
+ * nso_render_backward owns a private copy of the gradient buffers) */
+NSO_API void nso_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 NSO_API int nso_num_threads(void)
 {
 #ifdef _OPENMP

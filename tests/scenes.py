@@ -8,8 +8,28 @@ REF_BOUND = np.array([[-4.5, 3.82], [-1.5, 2.02], [-3.0, 2.76]], dtype=np.float3
 REF_GRID_SHAPES = {"coarse": (32, 5, 3, 8), "middle": (32, 18, 11, 26), "fine": (32, 36, 22, 52),
                    "color": (32, 36, 22, 52)}
 SMALL_GRID_SHAPES = {"coarse": (32, 3, 2, 4), "middle": (32, 6, 5, 7), "fine": (32, 9, 8, 11), "color": (32, 9, 8, 11)}
+# Scenes the reference has no configuration for (BASELINE.json configs[2..4]): bounds and intrinsics are
+# DECLARED HERE, in the harness -- ScanNet-scene0000-class room (K3), Replica-office0-class room (K4), TUM-fr1/desk-class volume (K5)
+K3_BOUND = np.array([[0.0, 8.6], [0.0, 8.9], [-0.3, 3.3]], dtype=np.float32)
+K4_BOUND = np.array([[-2.2, 3.8], [-1.7, 3.3], [-1.4, 1.6]], dtype=np.float32)
+K5_BOUND = np.array([[-3.5, 3.0], [-3.0, 3.0], [-3.0, 3.0]], dtype=np.float32)
+CAM_NICE_SLAM = dict(H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5)          # config/nice_slam.yaml:96-102 (K2, K4)
+CAM_SCANNET = dict(H=480, W=640, fx=577.590698, fy=578.729797, cx=318.905426, cy=242.683609)   # K3
+CAM_TUM = dict(H=480, W=640, fx=517.3, fy=516.5, cx=318.6, cy=255.3)                 # K5
+GRID_LEN = {"coarse": 2.0, "middle": 0.32, "fine": 0.16, "color": 0.16}              # config/nice_slam.yaml:7-11
 E_DIM, H_DIM = 93, 32
 LEVELS = ("coarse", "middle", "fine", "color")
+
+
+def grid_shapes_for(bound, c_dim=32, coarse_bound_enlarge=2):
+    """grid shapes [C,Z,Y,X] of src/main.cpp:34-75 for a bound (fp32 arithmetic, truncation by .item<int>())"""
+    b = np.asarray(bound, np.float32)
+    xyz = (b[:, 1] - b[:, 0]).astype(np.float32)
+    out = {}
+    for k in LEVELS:
+        v = xyz * np.float32(coarse_bound_enlarge) / np.float32(GRID_LEN[k]) if k == "coarse" else xyz / np.float32(GRID_LEN[k])
+        out[k] = (c_dim, int(v[2]), int(v[1]), int(v[0]))
+    return out
 
 
 def decoder_param_count(which):

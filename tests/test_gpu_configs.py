@@ -1,0 +1,420 @@
+"""GPU parity tests (-m gpu) at the sizes of BASELINE.json's configs: the HIP path, through the C-ABI, against the CPU oracle.
+
+    K2  config/nice_slam.yaml grids (36x22x52 ...), 1000 rays x 48: mapping steps + Adam on the reference grid shapes
+    K3  ScanNet-scene0000-class bound with its own grid shapes, 5000 rays x 48: fine and colour stages, mapping steps + Adam
+    K4  a 1250-ray shard rendered with the GLOBAL max(gt_depth) of a 10000-ray batch, and the 10000-ray batch on one GPU
+        (N > 8192: the batch maximum comes from k_depth_max instead of k_sample's waves)
+    K5  Tracker (200 rays) + Mapper with bundle adjustment (NSK_GRAD_RAYS | GRIDS | DECODERS) over two frames: poses and grids
+    and the renderer branches no other test reaches: perturb > 0 (stratified sampling), lindisp, nsk_raw2outputs.
+
+Tolerance: north_star's 1e-4 relative L2 on rendered depth / colour and on optimised grids, decoder and poses.  Bounds and
+intrinsics of K3-K5 are declared in tests/scenes.py (the reference holds no such configs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from gpu_util import cu, make_ctx
+from scenes import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+LR = {"fine": [0.0, 0.0, 0.005, 0.005, 0.0, 0.0], "color": [0.005, 0.0, 0.005, 0.005, 0.005, 0.0]}   # config/nice_slam.yaml:83-95
+LEVELS = {"fine": ("middle", "fine"), "color": ("middle", "fine", "color")}
+
+
+def _oracle_grads(o, sc, grids, decs, rays, stage, w_color, gmax):
+    op = o.opts(sc["bound"])
+    fw = o.render_forward(op, grids, decs, stage, rays["rays_o"], rays["rays_d"], rays["gt_depth"], gmax)
+    l, g_d, g_c = o.loss_map(fw["depth"], fw["rgb"], rays["gt_depth"], rays["gt_color"], w_color, stage == "color")
+    bw = o.render_backward(op, grids, decs, stage, rays["rays_o"], rays["rays_d"], rays["gt_depth"], gmax, g_c, g_d, None, want_rays=False)
+    return l, bw
+
+
+def _mapping_steps_vs_oracle(ctx, o, sc, rays, stage, steps, w_color=0.5, masks=None, gmax=-1.0, o64=None):
+    """`steps` mapping iterations (src/Mapper.cpp:430-446) on the GPU, every one of them checked against the oracle:
+
+      gradients   at the parameters the GPU holds before the step, the oracle's loss and its gradients of every trained level and of
+                  the colour decoder -- ALL rays, no filtering -- within 1e-3 relative L2, and within 1e-4 or at least as close to
+                  the fp64 oracle's as the fp32 oracle's are.  (Measured 1e-6 .. 3e-4: of the ~10^8 ReLU inputs of a batch a few
+                  dozen lie within rounding of zero, and the two fp32 evaluations put them on different sides of the kink; the
+                  strict 1e-4 bound on rays without such inputs is test_k2_gradients_strict_on_nonfragile_rays.)
+      Adam        the oracle's Adam applied to the GPU's own gradient must give the parameters the GPU holds after nsk_adam_step, to
+                  1e-6 (masked voxels untouched, moments carried across the steps);
+      free run    the oracle iterating on its own from the same start: Adam divides by |g| + 1e-8, so an element whose gradient is the
+                  rounding-sized remainder of hundreds of cancelling terms (voxels next to a camera) moves by +lr or -lr whichever way
+                  the last bit falls -- the fp32 and fp64 oracles themselves part there.  Such elements are counted (< 0.2 %), all
+                  others must agree within 3e-3.
+    The first two arms pin every step's arithmetic; the last one shows the trajectories stay together."""
+    lr = LR[stage]
+    levels = LEVELS[stage]
+    if gmax < 0:
+        gmax = float(np.max(rays["gt_depth"]))            # the batch statistic stays that of the whole batch when rays are dropped below
+    all_rays = rays
+    dropped = 0
+    loss_t = torch.zeros(1, device="cuda")
+    flags = 3 if stage == "color" else 1
+    grp = {"middle": 2, "fine": 3, "color": 4}
+    mom = {k: (np.zeros(sc["grids"][k].shape, np.float32), np.zeros(sc["grids"][k].shape, np.float32)) for k in levels}
+    dm, dv = np.zeros_like(sc["decoders"]["color"]), np.zeros_like(sc["decoders"]["color"])
+    free = [dict(o=oo, grids={k: v.astype(oo.dt).copy() for k, v in sc["grids"].items()}, decs={k: v.astype(oo.dt).copy() for k, v in sc["decoders"].items()},
+                 mom={k: (np.zeros(sc["grids"][k].shape, oo.dt), np.zeros(sc["grids"][k].shape, oo.dt)) for k in levels},
+                 dm=np.zeros(sc["decoders"]["color"].shape, oo.dt), dv=np.zeros(sc["decoders"]["color"].shape, oo.dt)) for oo in ([o] + ([o64] if o64 is not None else []))]
+    worst_g, worst_a = 0.0, 0.0
+    for step in range(1, steps + 1):
+        grids = dict(sc["grids"]); decs = dict(sc["decoders"])
+        for k in levels:
+            grids[k] = ctx.grid_download(k)
+        if stage == "color":
+            decs["color"] = ctx.decoder_download("color")
+        # The L1 losses (src/Mapper.cpp:435-442) have a kink of their own: a ray whose depth or colour residual is within rounding of
+        # zero gets gradient +1 or -1 depending on the last bit (seen: one ray at step 3 changed a level's gradient by 1.4 %).  Such
+        # rays are taken out of this step's batch -- on both sides -- and counted.
+        fw0 = o.render_forward(o.opts(sc["bound"]), grids, decs, stage, all_rays["rays_o"], all_rays["rays_d"], all_rays["gt_depth"], gmax)
+        res_d = np.abs(all_rays["gt_depth"] - fw0["depth"])
+        amb = (all_rays["gt_depth"] > 0) & (res_d < 2e-5 * np.maximum(1.0, np.abs(all_rays["gt_depth"])))
+        if stage == "color":
+            amb |= (np.abs(all_rays["gt_color"] - fw0["rgb"]) < 2e-6).any(axis=1)
+        dropped += int(amb.sum())
+        assert amb.mean() < 0.02
+        rays = {k: (v[~amb] if isinstance(v, np.ndarray) and v.shape[:1] == amb.shape else v) for k, v in all_rays.items()}
+        ro, rd, gd, gc = cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"]), cu(rays["gt_color"])
+        ctx.map_step(stage, ro, rd, gd, gc, gmax, w_color, stage == "color", flags=flags, loss=loss_t)
+        g_gpu = {k: ctx.grid_download(k, grad=True) for k in levels}
+        gdec_gpu = ctx.decoder_download("color", grad=True) if stage == "color" else None
+        l_ref, bw = _oracle_grads(o, sc, grids, decs, rays, stage, w_color, gmax)
+        bw64 = _oracle_grads(o64, sc, grids, decs, rays, stage, w_color, gmax)[1] if o64 is not None else None
+        assert abs(float(loss_t) - l_ref) < 2e-5 * abs(l_ref), (step, float(loss_t), l_ref)
+        pairs = [("grid_" + k, g_gpu[k], bw["g_grids"][k], bw64["g_grids"][k] if bw64 else None) for k in levels]
+        if stage == "color":
+            pairs.append(("colour decoder", gdec_gpu, bw["g_decoders"]["color"], bw64["g_decoders"]["color"] if bw64 else None))
+        for name, got_g, ref_g, ref64_g in pairs:
+            e = rel_l2(got_g, ref_g)
+            if os.environ.get("NSK_TEST_VERBOSE"):
+                dd = np.abs(got_g - ref_g); ii = np.unravel_index(np.argmax(dd), dd.shape)
+                print("step %d %s: hip-vs-f32 %.2e%s; worst element %s hip %.4e f32 %.4e" % (step, name, e, "" if ref64_g is None else " f32-vs-f64 %.2e" % rel_l2(ref_g, ref64_g),
+                                                                                          tuple(int(x) for x in ii), got_g[ii], ref_g[ii]))
+            worst_g = max(worst_g, e)
+            assert e < 10 * TOL, "step %d: d loss / d %s off by %.2e (all %d rays)" % (step, name, e, rays["rays_o"].shape[0])
+            if ref64_g is not None:
+                e64, eo = rel_l2(got_g, ref64_g), rel_l2(ref_g, ref64_g)
+                assert e < TOL or e64 < 2 * eo + TOL, "step %d: d loss / d %s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (step, name, e, e64, eo)
+        # the oracle's Adam on the GPU's gradient = what nsk_adam_step must produce
+        expect = {}
+        for k in levels:
+            p = grids[k].copy()
+            vm = None if masks is None else np.broadcast_to(masks[k][None], p.shape)
+            o.adam_step(p, g_gpu[k], mom[k][0], mom[k][1], lr[grp[k]], step, mask=vm)
+            expect[k] = p
+        if stage == "color":
+            pdec = decs["color"].copy()
+            o.adam_step(pdec, gdec_gpu, dm, dv, lr[0], step)
+        ctx.adam_step(lr)
+        for k in levels:
+            got = ctx.grid_download(k)
+            e = rel_l2(got - grids[k], expect[k] - grids[k])
+            worst_a = max(worst_a, e)
+            assert e < 1e-5, "step %d: Adam update of grid_%s off by %.2e" % (step, k, e)
+            if masks is not None:
+                assert np.array_equal(got[:, ~masks[k]], sc["grids"][k][:, ~masks[k]])      # unmarked voxels never move
+        if stage == "color":
+            e = rel_l2(ctx.decoder_download("color") - decs["color"], pdec - decs["color"])
+            worst_a = max(worst_a, e)
+            assert e < 2e-5, "step %d: Adam update of the colour decoder off by %.2e" % (step, e)
+        for F in free:                                   # the oracles iterating on their own
+            oo = F["o"]
+            _, bwf = _oracle_grads(oo, sc, F["grids"], F["decs"], all_rays, stage, w_color, gmax)
+            for k in levels:
+                vm = None if masks is None else np.broadcast_to(masks[k][None], F["grids"][k].shape)
+                oo.adam_step(F["grids"][k], bwf["g_grids"][k], F["mom"][k][0], F["mom"][k][1], lr[grp[k]], step, mask=vm)
+            if stage == "color":
+                oo.adam_step(F["decs"]["color"], bwf["g_decoders"]["color"], F["dm"], F["dv"], lr[0], step)
+    ctx.sync()
+    report = ["gradients <= %.1e, Adam <= %.1e over %d steps (%d rays with a loss residual within rounding of zero left out)" % (worst_g, worst_a, steps, dropped)]
+    for k in levels:
+        got = ctx.grid_download(k)
+        assert np.abs(got - sc["grids"][k]).max() > 1e-3, k
+        # free run: the two trajectories part only on the elements whose gradient sign is decided by rounding (a few per level, each
+        # then +-lr apart): those are counted, the rest must agree
+        ref_k = free[0]["grids"][k]
+        far = np.abs(got - ref_k) > 0.1 * 0.005
+        assert far.mean() < 2e-3, (k, far.mean())
+        e = rel_l2(got[~far], ref_k[~far])
+        assert e < 30 * TOL, (k, e)
+        report.append("%s free run: %d of %d elements took the other sign, the rest within %.1e%s" % (
+            k, far.sum(), far.size, e, "" if len(free) < 2 else " (fp32 and fp64 oracles: %d apart)" % (np.abs(ref_k - free[1]["grids"][k]) > 0.1 * 0.005).sum()))
+    if stage == "color":
+        assert rel_l2(ctx.decoder_download("color"), free[0]["decs"]["color"]) < 50 * TOL
+    for k in ("middle", "fine"):
+        assert np.array_equal(ctx.decoder_download(k), sc["decoders"][k])        # frozen decoders never move (fix_fine)
+    print("; ".join(report))
+
+
+@pytest.mark.parametrize("sort_mode", [-1, 0])
+def test_k2_full_size_mapping_steps(sort_mode, oracle32, oracle64):
+    """configs[1]: reference grid shapes (src/main.cpp:33-78), 1000 rays x 48, colour stage, 3 iterations + Adam, random frustum masks;
+    both sample orders (cell-sorted = what a mapping step uses, ray order = what bundle adjustment uses)"""
+    sc = scenes.make_scene(51)
+    rays = scenes.make_rays(52, 1000, sc["bound"], n_frames=5)
+    rng = np.random.default_rng(5)
+    masks = {k: rng.random(sc["grids"][k].shape[1:]) < 0.8 for k in ("middle", "fine", "color")}
+    ctx = make_ctx(sc, trainable=["color"])
+    ctx.set_sort_mode(sort_mode)
+    for k, m in masks.items():
+        ctx.set_mask(k, m)
+    _mapping_steps_vs_oracle(ctx, oracle32, sc, rays, "color", 3, masks=masks, o64=oracle64)
+
+
+def test_k2_gradients_strict_on_nonfragile_rays(oracle32, oracle64):
+    """The strict arm of the gradient contract at full K2 size: rays none of whose ReLU inputs lies within 2e-5 of zero
+    (oracle/nso.c nso_ray_fragility, evaluated in fp64) -- there the gradient is a smooth function of the inputs and the HIP path must
+    match the fp32 oracle within 1e-4 relative L2 on every trained level and the colour decoder, no escape.  The share of rays kept is
+    asserted and printed."""
+    sc = scenes.make_scene(51)
+    rays = scenes.make_rays(52, 1000, sc["bound"], n_frames=5)
+    frag = oracle64.ray_fragility(oracle64.opts(sc["bound"]), sc["grids"], sc["decoders"], "color", rays["rays_o"], rays["rays_d"], rays["gt_depth"])
+    keep = frag > 2e-5
+    assert keep.mean() > 0.6, keep.mean()
+    sub = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == keep.shape else v) for k, v in rays.items()}
+    gmax = float(rays["gt_depth"].max())                                       # (keep the batch statistic of the full batch)
+    for sort_mode in (-1, 0):
+        ctx = make_ctx(sc, trainable=["color"])
+        ctx.set_sort_mode(sort_mode)
+        loss_t = torch.zeros(1, device="cuda")
+        ctx.map_step("color", cu(sub["rays_o"]), cu(sub["rays_d"]), cu(sub["gt_depth"]), cu(sub["gt_color"]), gmax, 0.5, True, flags=3, loss=loss_t)
+        l_ref, bw = _oracle_grads(oracle32, sc, sc["grids"], sc["decoders"], sub, "color", 0.5, gmax)
+        assert abs(float(loss_t) - l_ref) < 2e-5 * abs(l_ref)
+        errs = {k: rel_l2(ctx.grid_download(k, grad=True), bw["g_grids"][k]) for k in LEVELS["color"]}
+        errs["colour decoder"] = rel_l2(ctx.decoder_download("color", grad=True), bw["g_decoders"]["color"])
+        print("sort mode %d: %d of %d rays kept (%.0f %%), gradient errors %s" % (sort_mode, keep.sum(), keep.size, 100 * keep.mean(),
+                                                                             {k: "%.1e" % v for k, v in errs.items()}))
+        for k, e in errs.items():
+            assert e < TOL, (sort_mode, k, e)
+
+
+@pytest.mark.parametrize("stage", ["fine", "color"])
+def test_k3_scannet_class_mapping_steps(stage, oracle32, oracle64):
+    """configs[2]: ScanNet-scene0000-class bound, grid shapes of src/main.cpp:34-75 for it (22x55x53 fine), 5000 rays x 48,
+    fine and colour stages, 3 iterations + Adam"""
+    shapes = scenes.grid_shapes_for(scenes.K3_BOUND)
+    assert shapes["fine"] == (32, 22, 55, 53) and shapes["middle"] == (32, 11, 27, 26)
+    sc = scenes.make_scene(61, shapes, bound=scenes.K3_BOUND)
+    rays = scenes.make_rays(62, 5000, sc["bound"], n_frames=5, **scenes.CAM_SCANNET)
+    ctx = make_ctx(sc, trainable=["color"] if stage == "color" else [])
+    _mapping_steps_vs_oracle(ctx, oracle32, sc, rays, stage, 3, o64=oracle64)
+
+
+def test_k4_shard_with_global_depth_max_and_full_batch(oracle32, oracle64):
+    """configs[3]: 10000 rays of an office0-class room; (i) the whole batch on one GPU with the batch maximum of gt_depth taken on the
+    device (N > 8192 -> k_depth_max), (ii) rank 3's 1250-ray shard rendered with the GLOBAL maximum passed in: both must equal the
+    oracle's render of the whole batch (src/Renderer.cpp:76,93 couple all rays through max(gt_depth))"""
+    sc = scenes.make_scene(71, scenes.grid_shapes_for(scenes.K4_BOUND), bound=scenes.K4_BOUND)
+    rays = scenes.make_rays(72, 10000, sc["bound"], n_frames=5, **scenes.CAM_NICE_SLAM)
+    # make the global maximum live outside the shard that is tested, so a shard-local maximum would be wrong
+    lo, hi = 3 * 1250, 4 * 1250
+    gd = rays["gt_depth"].copy()
+    far = int(np.argmax(gd))
+    if lo <= far < hi:
+        gd[far], gd[0] = gd[0], gd[far]
+    gd[7] = float(gd.max()) * 1.5
+    rays["gt_depth"] = gd
+    gmax = float(gd.max())
+    assert gd[lo:hi].max() < gmax
+    o = oracle32
+    ref = o.render_forward(o.opts(sc["bound"]), sc["grids"], sc["decoders"], "color", rays["rays_o"], rays["rays_d"], gd)
+    ctx = make_ctx(sc)
+    rgb, depth, var, w = ctx.render_forward("color", cu(rays["rays_o"]), cu(rays["rays_d"]), cu(gd), -1.0)       # device-side maximum
+    assert rel_l2(depth.cpu().numpy(), ref["depth"]) < TOL and rel_l2(rgb.cpu().numpy(), ref["rgb"]) < TOL
+    assert rel_l2(var.cpu().numpy(), ref["var"]) < TOL and rel_l2(w.cpu().numpy(), ref["weights"]) < TOL
+    sl = slice(lo, hi)
+    rgb_s, depth_s, var_s, w_s = ctx.render_forward("color", cu(rays["rays_o"][sl]), cu(rays["rays_d"][sl]), cu(gd[sl]), gmax)
+    assert rel_l2(depth_s.cpu().numpy(), ref["depth"][sl]) < TOL and rel_l2(rgb_s.cpu().numpy(), ref["rgb"][sl]) < TOL
+    assert rel_l2(w_s.cpu().numpy(), ref["weights"][sl]) < TOL
+    # and the shard-local maximum would NOT have matched (the test is sensitive to the coupling)
+    _, depth_l, _, w_l = ctx.render_forward("color", cu(rays["rays_o"][sl]), cu(rays["rays_d"][sl]), cu(gd[sl]), -1.0)
+    assert rel_l2(w_l.cpu().numpy(), ref["weights"][sl]) > 10 * TOL
+    # one mapping step of the shard with the global maximum against the oracle's step on the same shard
+    shard = {k: (v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (10000,) else v) for k, v in rays.items()}
+    shard["gt_depth"] = gd[sl]
+    ctx2 = make_ctx(sc, trainable=["color"])
+    _mapping_steps_vs_oracle(ctx2, o, sc, shard, "color", 2, gmax=gmax, o64=oracle64)
+
+
+def test_k4_full_batch_mapping_step(oracle32, oracle64):
+    """10000 rays x 48 in one launch (N > 8192 in nsk_map_step: k_depth_max feeds k_sample; 30000 tiles per decoder): one colour-stage
+    iteration + Adam against the oracle"""
+    sc = scenes.make_scene(73, scenes.grid_shapes_for(scenes.K4_BOUND), bound=scenes.K4_BOUND)
+    rays = scenes.make_rays(74, 10000, sc["bound"], n_frames=5, **scenes.CAM_NICE_SLAM)
+    ctx = make_ctx(sc, trainable=["color"])
+    _mapping_steps_vs_oracle(ctx, oracle32, sc, rays, "color", 1, o64=oracle64)
+
+
+def _quat_cam(c2w, dq=1.0, dt=(0.0, 0.0, 0.0)):
+    R = c2w[:3, :3].astype(np.float64)
+    qw = np.sqrt(max(1e-12, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    q = np.array([qw, (R[2, 1] - R[1, 2]) / (4 * qw), (R[0, 2] - R[2, 0]) / (4 * qw), (R[1, 0] - R[0, 1]) / (4 * qw)])
+    return np.concatenate([q * dq, c2w[:3, 3] + np.asarray(dt)]).astype(np.float32)
+
+
+def test_k5_tracker_then_mapper_with_bundle_adjustment(oracle32, oracle64):
+    """configs[4]: the full loop on two frames of a TUM-fr1/desk-class volume: Tracker::optimize_cam_in_batch on 200 rays (pose of the
+    current frame, src/Tracker.cpp:41-89), then Mapper::optimize_map with BA (src/Mapper.cpp:305-329,366-368,467-489): rays of the
+    keyframe (fixed pose: the oldest frame) and of the current frame (pose optimised jointly with grids and colour decoder), all
+    gradients from ONE nsk_map_step with NSK_GRAD_RAYS | GRIDS | DECODERS.  Pixel indices are inputs (torch::randint cannot be matched)."""
+    cam = scenes.CAM_TUM
+    intr = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    sc = scenes.make_scene(81, scenes.grid_shapes_for(scenes.K5_BOUND), bound=scenes.K5_BOUND, grid_std=0.2, bias_std=0.05)
+    b = sc["bound"]
+    r_kf = scenes.make_rays(82, 500, b, n_frames=1, edge=20, **cam)          # keyframe rays (pose fixed)
+    r_cur = scenes.make_rays(83, 500, b, n_frames=1, edge=20, **cam)         # current frame, mapper rays
+    r_trk = scenes.make_rays(84, 200, b, n_frames=1, edge=20, **cam)         # current frame, tracker rays
+    c2w_cur = r_cur["c2w"][0]
+    # tracker and mapper rays of the current frame must come from the same camera: regenerate the tracker's ground truth from c2w_cur
+    r_trk = scenes.make_rays(83, 500, b, n_frames=1, edge=20, **cam)
+    tsel = np.arange(0, 500, 2)[:200]
+    cam0 = _quat_cam(c2w_cur, 1.2, (0.015, -0.01, 0.02))                     # start from a perturbed, un-normalised pose
+    kf_c2w = r_kf["c2w"][0]
+    TRK_IT, MAP_IT, LR_CAM, BA_LR = 3, 3, 1e-2, 1e-3
+
+    def run(o, on_gpu):
+        dt = np.float32 if on_gpu else o.dt
+        camv = cam0.astype(dt).copy()
+        # ---------------- Tracker ----------------
+        pi, pj, gt_d, gt_c = r_trk["pix_i"][tsel], r_trk["pix_j"][tsel], r_trk["gt_depth"][tsel], r_trk["gt_color"][tsel]
+        if on_gpu:
+            ctx = make_ctx(sc, trainable=["color"])
+            cam_t = cu(camv); m_t = torch.zeros(7, device="cuda"); v_t = torch.zeros(7, device="cuda")
+            pi_t, pj_t, gd_t, gc_t = cu(pi, torch.int32), cu(pj, torch.int32), cu(gt_d), cu(gt_c)
+            loss_t = torch.zeros(1, device="cuda")
+            for step in range(1, TRK_IT + 1):
+                ro, rd = ctx.rays_from_camera(pi_t, pj_t, intr, cam_t)
+                keep = ctx.inside_filter(ro, rd, gd_t)
+                assert bool(keep.all())                                      # (rays were generated inside the room: nothing to compact)
+                g_ro = torch.empty_like(ro); g_rd = torch.empty_like(rd)
+                ctx.track_step("color", ro, rd, gd_t, gc_t, -1.0, 0.5, True, True, True, flags=4, loss=loss_t, g_rays=(g_ro, g_rd))
+                ctx.pose_step(pi_t, pj_t, intr, g_ro, g_rd, cam_t, m_t, v_t, LR_CAM, step)
+            camv = cam_t.cpu().numpy()
+        else:
+            m, v = np.zeros(7, dt), np.zeros(7, dt)
+            for step in range(1, TRK_IT + 1):
+                c2w = o.camera_from_tensor(camv)
+                ro, rd = o.rays_from_pixels(pi, pj, *intr, c2w)
+                assert o.inside_filter(b, ro, rd, gt_d).all()
+                op = o.opts(b)
+                fw = o.render_forward(op, sc["grids"], sc["decoders"], "color", ro, rd, gt_d)
+                _, gD, gC, gV = o.loss_track(fw["depth"], fw["rgb"], fw["var"], gt_d, gt_c, 0.5, True, True, True)
+                bw = o.render_backward(op, sc["grids"], sc["decoders"], "color", ro, rd, gt_d, -1.0, gC, gD, None, want_grids=False, want_decoders=False)
+                g_cam = o.camera_backward(camv, o.rays_backward(pi, pj, *intr, bw["g_rays_o"], bw["g_rays_d"]))
+                o.adam_step(camv, g_cam, m, v, LR_CAM, step)
+        cam_tracked = camv.copy()
+        # ---------------- Mapper with BA ----------------
+        pi_c, pj_c = r_cur["pix_i"], r_cur["pix_j"]
+        gd_all = np.concatenate([r_kf["gt_depth"], r_cur["gt_depth"]]).astype(np.float32)
+        gc_all = np.concatenate([r_kf["gt_color"], r_cur["gt_color"]]).astype(np.float32)
+        n_kf = r_kf["rays_o"].shape[0]
+        if on_gpu:
+            cam_t = cu(camv); m_t = torch.zeros(7, device="cuda"); v_t = torch.zeros(7, device="cuda")
+            pi_t, pj_t = cu(pi_c, torch.int32), cu(pj_c, torch.int32)
+            ro_k, rd_k = cu(r_kf["rays_o"]), cu(r_kf["rays_d"])
+            gd_t, gc_t = cu(gd_all), cu(gc_all)
+            loss_t = torch.zeros(1, device="cuda")
+            for step in range(1, MAP_IT + 1):
+                ro_c, rd_c = ctx.rays_from_camera(pi_t, pj_t, intr, cam_t)
+                ro = torch.cat([ro_k, ro_c]).contiguous(); rd = torch.cat([rd_k, rd_c]).contiguous()
+                g_ro = torch.empty_like(ro); g_rd = torch.empty_like(rd)
+                ctx.map_step("color", ro, rd, gd_t, gc_t, -1.0, 0.5, True, flags=7, loss=loss_t, g_rays=(g_ro, g_rd))
+                ctx.adam_step(LR["color"])
+                ctx.pose_step(pi_t, pj_t, intr, g_ro[n_kf:].contiguous(), g_rd[n_kf:].contiguous(), cam_t, m_t, v_t, BA_LR, step)
+            ctx.sync()
+            return cam_tracked, cam_t.cpu().numpy(), {k: ctx.grid_download(k) for k in LEVELS["color"]}, ctx.decoder_download("color")
+        grids = {k: v.astype(dt).copy() for k, v in sc["grids"].items()}
+        decs = {k: v.astype(dt).copy() for k, v in sc["decoders"].items()}
+        mom = {k: (np.zeros_like(grids[k]), np.zeros_like(grids[k])) for k in LEVELS["color"]}
+        dm, dv = np.zeros_like(decs["color"]), np.zeros_like(decs["color"])
+        m, v = np.zeros(7, dt), np.zeros(7, dt)
+        op = o.opts(b)
+        for step in range(1, MAP_IT + 1):
+            c2w = o.camera_from_tensor(camv)
+            ro_c, rd_c = o.rays_from_pixels(pi_c, pj_c, *intr, c2w)
+            ro = np.concatenate([r_kf["rays_o"].astype(dt), ro_c]); rd = np.concatenate([r_kf["rays_d"].astype(dt), rd_c])
+            fw = o.render_forward(op, grids, decs, "color", ro, rd, gd_all)
+            _, g_d, g_c = o.loss_map(fw["depth"], fw["rgb"], gd_all, gc_all, 0.5, True)
+            bw = o.render_backward(op, grids, decs, "color", ro, rd, gd_all, -1.0, g_c, g_d, None)
+            for k in mom:
+                o.adam_step(grids[k], bw["g_grids"][k], mom[k][0], mom[k][1], 0.005, step)
+            o.adam_step(decs["color"], bw["g_decoders"]["color"], dm, dv, 0.005, step)
+            g_cam = o.camera_backward(camv, o.rays_backward(pi_c, pj_c, *intr, bw["g_rays_o"][n_kf:], bw["g_rays_d"][n_kf:]))
+            o.adam_step(camv, g_cam, m, v, BA_LR, step)
+        return cam_tracked, camv, grids, decs["color"]
+
+    trk_g, cam_g, grids_g, dec_g = run(None, True)
+    trk_32, cam_32, grids_32, dec_32 = run(oracle32, False)
+    trk_64, cam_64, grids_64, dec_64 = run(oracle64, False)
+    assert np.abs(trk_32 - cam0).max() > 1e-3 and np.abs(cam_32 - trk_32).max() > 1e-4        # both optimisers moved the pose
+    # poses: 1e-4 against the fp32 oracle, or at least as close to the fp64 run as the fp32 oracle is (pose gradients sum ~10^4
+    # ReLU-kinked terms: SURVEY.md section 8e item 3); grids and decoder: 1e-4
+    for name, got, r32, r64 in (("tracked pose", trk_g, trk_32, trk_64), ("BA pose", cam_g, cam_32, cam_64)):
+        e, e64, eo = rel_l2(got, r32), rel_l2(got, r64), rel_l2(r32, r64)
+        assert e < TOL or e64 < max(TOL, 2 * eo), "%s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (name, e, e64, eo)
+    for k in LEVELS["color"]:          # (rounding-sized gradients under Adam: see _mapping_steps_vs_oracle)
+        e, e64, eo = rel_l2(grids_g[k], grids_32[k]), rel_l2(grids_g[k], grids_64[k]), rel_l2(grids_32[k], grids_64[k])
+        assert e < TOL or e64 < 2 * eo + TOL, "%s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (k, e, e64, eo)
+        assert e < 200 * TOL, (k, e)
+    e, e64, eo = rel_l2(dec_g, dec_32), rel_l2(dec_g, dec_64), rel_l2(dec_32, dec_64)
+    assert e < TOL or e64 < 2 * eo + TOL, "colour decoder: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (e, e64, eo)
+    assert e < 50 * TOL
+    print("K5: tracked pose %.1e, BA pose %.1e, colour decoder %.1e (fp32 vs fp64 oracle %.1e)" % (rel_l2(trk_g, trk_32), rel_l2(cam_g, cam_32), e, eo))
+
+
+@pytest.mark.parametrize("perturb,lindisp", [(1.0, False), (0.0, True), (1.0, True)])
+@pytest.mark.parametrize("with_gt", [True, False])
+def test_stratified_and_lindisp_sampling(perturb, lindisp, with_gt, oracle32):
+    """src/Renderer.cpp:104-117: lindisp spacing and stratified perturbation (north_star: "per-ray stratified sampling").  The
+    perturbation draws from a counter-based hash of (seed, ray, sample) -- the oracle restates the same hash (oracle/nso.c hash_unit);
+    torch::rand's stream cannot be matched."""
+    sc = scenes.make_scene(3, scenes.SMALL_GRID_SHAPES, grid_std=0.3, bias_std=0.1)
+    # (lindisp divides by near = 0.01 gt_depth: rays with gt_depth = 0 are NaN in the reference as well, so none here)
+    rays = scenes.make_rays(4, 150, sc["bound"], n_frames=2, zero_frac=0.0 if lindisp else 0.1)
+    gd = rays["gt_depth"] if with_gt else None
+    o = oracle32
+    op = o.opts(sc["bound"], lindisp=lindisp, perturb=perturb, seed=1234)
+    ref = o.render_forward(op, sc["grids"], sc["decoders"], "color", rays["rays_o"], rays["rays_d"], gd, want_aux=True)
+    base = o.render_forward(o.opts(sc["bound"]), sc["grids"], sc["decoders"], "color", rays["rays_o"], rays["rays_d"], gd, want_aux=True)
+    assert np.abs(ref["z"] - base["z"]).max() > 1e-3                          # the option changes the samples
+    ctx = make_ctx(sc)
+    ctx.set_render_opts(lindisp=lindisp, perturb=perturb, seed=1234)
+    rgb, depth, var, w = ctx.render_forward("color", cu(rays["rays_o"]), cu(rays["rays_d"]), None if gd is None else cu(gd))
+    assert rel_l2(depth.cpu().numpy(), ref["depth"]) < TOL and rel_l2(rgb.cpu().numpy(), ref["rgb"]) < TOL
+    assert rel_l2(var.cpu().numpy(), ref["var"]) < TOL and rel_l2(w.cpu().numpy(), ref["weights"]) < TOL
+    # a different seed gives different samples; the same seed the same render
+    if perturb > 0:
+        ctx.set_render_opts(lindisp=lindisp, perturb=perturb, seed=99)
+        _, depth2, _, _ = ctx.render_forward("color", cu(rays["rays_o"]), cu(rays["rays_d"]), None if gd is None else cu(gd))
+        assert rel_l2(depth2.cpu().numpy(), ref["depth"]) > 1e-4
+
+
+@pytest.mark.parametrize("occupancy", [False, True])
+def test_raw2outputs_standalone(occupancy, oracle32):
+    """raw2outputs_nerf_color (include/torchlib/utils.h:148-172) through nsk_raw2outputs: raw and z of the oracle's render in, the
+    oracle's composited outputs out; both alpha branches"""
+    sc = scenes.make_scene(5, scenes.SMALL_GRID_SHAPES, grid_std=0.3, bias_std=0.1)
+    rays = scenes.make_rays(6, 131, sc["bound"], n_frames=2, zero_frac=0.1)
+    o = oracle32
+    fw = o.render_forward(o.opts(sc["bound"], occupancy=occupancy), sc["grids"], sc["decoders"], "color", rays["rays_o"], rays["rays_d"],
+                          rays["gt_depth"], want_aux=True)
+    ctx = make_ctx(sc)
+    rgb, depth, var, w = ctx.raw2outputs(cu(fw["raw"]), cu(fw["z"]), cu(rays["rays_d"]), occupancy)
+    assert rel_l2(depth.cpu().numpy(), fw["depth"]) < 1e-5 and rel_l2(rgb.cpu().numpy(), fw["rgb"]) < 1e-5
+    assert rel_l2(var.cpu().numpy(), fw["var"]) < 1e-5 and rel_l2(w.cpu().numpy(), fw["weights"]) < 1e-5
+    # 16-sample rays (K1 shape) and a single ray
+    z16 = np.sort(np.random.default_rng(0).uniform(0.1, 3.0, (3, 16)).astype(np.float32), axis=1)
+    raw16 = np.random.default_rng(1).standard_normal((3, 16, 4)).astype(np.float32)
+    d3 = np.array([[0.1, 0.2, -1.0], [0.0, 0.0, -2.0], [1.0, 1.0, 1.0]], np.float32)
+    rgb, depth, var, w = ctx.raw2outputs(cu(raw16), cu(z16), cu(d3), occupancy)
+    dist = np.concatenate([z16[:, 1:] - z16[:, :-1], np.full((3, 1), 1e10, np.float32)], 1) * np.linalg.norm(d3, axis=1, keepdims=True)
+    alpha = 1 / (1 + np.exp(-10.0 * raw16[..., 3])) if occupancy else 1 - np.exp(-np.maximum(raw16[..., 3], 0) * dist)
+    T = np.cumprod(np.concatenate([np.ones((3, 1)), 1 - alpha + 1e-10], 1), 1)[:, :-1]
+    wref = alpha * T
+    assert rel_l2(w.cpu().numpy(), wref) < 1e-5 and rel_l2(depth.cpu().numpy(), (wref * z16).sum(1)) < 1e-5

@@ -56,6 +56,31 @@ def test_forward_matches_golden(path):
         assert rel_l2(rgb.cpu().numpy(), g["rgb"]) < TOL
 
 
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[7:-4] for p in GOLDEN])
+def test_backward_matches_golden(path):
+    """the backward fields of the committed golden vectors (fp64 autograd over the reference's ATen op sequence, tests/golden/
+    make_golden.py): d L / d grids, d L / d every decoder of the stage (all trainable at once: the fine decoder's trainable body and
+    the one-launch-per-decoder path run here), d L / d rays -- all 24 rays, no filtering, 1e-4 relative L2"""
+    z = np.load(path, allow_pickle=False)
+    g = {k: z[k] for k in z.files}
+    stage = str(g["stage"])
+    sc = dict(bound=g["bound"], grids={k: g["grid_" + k] for k in scenes.LEVELS}, decoders={k: g["dec_" + k] for k in scenes.LEVELS})
+    levels = stage_levels(stage)
+    ctx = make_ctx(sc, occupancy=bool(g["occupancy"]), trainable=levels)
+    gd = cu(g["gt_depth"]) if bool(g["with_gt"]) else None
+    g_ro, g_rd = ctx.render_backward(stage, cu(g["rays_o"]), cu(g["rays_d"]), gd, -1.0, cu(g["g_rgb"]), cu(g["g_depth"]), cu(g["g_var"]), flags=7)
+    ctx.sync()
+    errs = {"rays_o": rel_l2(g_ro.cpu().numpy(), g["g_rays_o"]), "rays_d": rel_l2(g_rd.cpu().numpy(), g["g_rays_d"])}
+    for k in levels:
+        if "g_grid_" + k in g:
+            errs["grid_" + k] = rel_l2(ctx.grid_download(k, grad=True), g["g_grid_" + k])
+        if "g_dec_" + k in g:
+            errs["dec_" + k] = rel_l2(ctx.decoder_download(k, grad=True), g["g_dec_" + k])
+    assert len(errs) >= 4, errs
+    for k, e in errs.items():
+        assert e < TOL, (k, e, errs)
+
+
 def test_eval_points_matches_oracle(oracle32):
     """Renderer::eval_points: raw = (rgb, occ), occ = 100 outside the bound"""
     sc = _scene(5)
@@ -80,7 +105,7 @@ def test_eval_points_matches_oracle(oracle32):
     assert rel_l2(raw, fw["raw"].reshape(-1, 4)) < TOL
 
 
-def _backward_case(stage, with_gt, occupancy, oracle32, oracle64, trainable, n_rays=96, seed=3, tau=2e-5):
+def _backward_case(stage, with_gt, occupancy, oracle32, oracle64, trainable, n_rays=96, seed=3, tau=2e-5, filtered=True):
     sc = _scene(seed)
     rays = scenes.make_rays(seed + 1, n_rays, sc["bound"], n_frames=2, zero_frac=0.1)
     gd = rays["gt_depth"] if with_gt else None
@@ -89,7 +114,7 @@ def _backward_case(stage, with_gt, occupancy, oracle32, oracle64, trainable, n_r
     g_rgb, g_d, g_v = rng.standard_normal((N, 3)).astype(np.float32), rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
     # drop rays that sit on a ReLU kink (their gradient is not a function of the inputs to within rounding)
     frag = oracle64.ray_fragility(oracle64.opts(sc["bound"], occupancy=occupancy), sc["grids"], sc["decoders"], stage, rays["rays_o"], rays["rays_d"], gd)
-    keep = frag > tau
+    keep = frag > tau if filtered else np.ones(N, bool)
     assert keep.mean() > 0.5
     g_rgb[~keep] = 0; g_d[~keep] = 0; g_v[~keep] = 0
     op = oracle32.opts(sc["bound"], occupancy=occupancy)
@@ -106,20 +131,34 @@ def _backward_case(stage, with_gt, occupancy, oracle32, oracle64, trainable, n_r
             out["dec_" + k] = (ctx.decoder_download(k, grad=True), ref["g_decoders"][k], ref64["g_decoders"][k])
     out["rays_o"] = (g_ro.cpu().numpy(), ref["g_rays_o"], ref64["g_rays_o"])
     out["rays_d"] = (g_rd.cpu().numpy(), ref["g_rays_d"], ref64["g_rays_d"])
+    out["_kept"] = float(keep.mean())
     return out, ctx, sc
+
+
+def _assert_gradients(out, what):
+    """filtered rays (no ReLU input within 2e-5 of zero): strictly within 1e-4 of the fp32 oracle, no escape.  All rays: within 3e-3,
+    and within 1e-4 or within 5x of the fp32 oracle's own distance to the fp64 oracle.  A ReLU input within rounding of zero falls
+    on either side of the kink and switches one unit of one sample; the fp32 oracle differs from the fp64 one by such flips
+    (2e-4 .. 1e-3 of a gradient in these scenes), and the HIP path has proportionally more of them: its sin/cos is accurate to
+    1.4e-7 absolute (library sinf: 0.5 ulp), which puts its pre-activations ~1e-6 from the fp64 ones instead of ~3e-7."""
+    kept = out.pop("_kept")
+    for k, (got, ref, ref64) in out.items():
+        e, e64, eo = rel_l2(got, ref), rel_l2(got, ref64), rel_l2(ref, ref64)
+        msg = "%s %s (%.0f %% of the rays): hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (what, k, 100 * kept, e, e64, eo)
+        if what == "filtered":
+            assert e < TOL, msg
+        else:
+            assert e < 30 * TOL and (e < TOL or e64 < 5 * eo + TOL), msg
 
 
 @pytest.mark.parametrize("stage", ["coarse", "middle", "fine", "color"])
 @pytest.mark.parametrize("with_gt,occupancy", [(True, False), (False, True)])
 def test_backward_matches_oracle(stage, with_gt, occupancy, oracle32, oracle64):
     trainable = stage_levels(stage)
+    out_all, _, _ = _backward_case(stage, with_gt, occupancy, oracle32, oracle64, trainable, filtered=False)
+    _assert_gradients(out_all, "all rays")
     out, ctx, sc = _backward_case(stage, with_gt, occupancy, oracle32, oracle64, trainable)
-    for k, (got, ref, ref64) in out.items():
-        e = rel_l2(got, ref)
-        e64 = rel_l2(got, ref64)
-        eo = rel_l2(ref, ref64)
-        # within tolerance of the fp32 oracle, or at least as close to the fp64 truth as the fp32 oracle is
-        assert e < 5 * TOL or e64 < 2 * eo + TOL, "%s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (k, e, e64, eo)
+    _assert_gradients(out, "filtered")
     # untouched levels / frozen decoders keep zero gradient
     for k in scenes.LEVELS:
         if k not in stage_levels(stage):
@@ -129,6 +168,7 @@ def test_backward_matches_oracle(stage, with_gt, occupancy, oracle32, oracle64):
 
 def test_frozen_decoders_get_no_gradient_and_grads_accumulate(oracle32, oracle64):
     out, ctx, sc = _backward_case("color", True, False, oracle32, oracle64, trainable=["color"])
+    out.pop("_kept")
     assert np.abs(ctx.decoder_download("middle", grad=True)).max() == 0
     assert np.abs(ctx.decoder_download("fine", grad=True)).max() == 0
     g1 = ctx.grid_download("fine", grad=True)
@@ -428,10 +468,10 @@ def test_backward_with_several_iterations_per_workgroup(oracle32, oracle64):
     """5000 rays = 15000 tiles: the trainable role runs more than two panel iterations per workgroup (staged loads, image
     swaps, resident embedding rows and the scatter all cross iteration boundaries); colour decoder trainable only, as in
     the mapping step"""
+    out_all, _, _ = _backward_case("color", True, False, oracle32, oracle64, ["color"], n_rays=5000, seed=31, filtered=False)
+    _assert_gradients(out_all, "all rays")
     out, ctx, sc = _backward_case("color", True, False, oracle32, oracle64, ["color"], n_rays=5000, seed=31)
-    for k, (got, ref, ref64) in out.items():
-        e, e64, eo = rel_l2(got, ref), rel_l2(got, ref64), rel_l2(ref, ref64)
-        assert e < 5 * TOL or e64 < 2 * eo + TOL, "%s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (k, e, e64, eo)
+    _assert_gradients(out, "filtered")
 
 
 def test_graph_replay_matches_eager_steps(oracle32):

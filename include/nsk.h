@@ -211,6 +211,12 @@ int nsk_camera_backward(nsk_ctx* ctx, const float* d_cam, const float* d_g_c2w, 
 /* inside-bbox pre-filter (src/Mapper.cpp:416-427, src/Tracker.cpp:48-58): d_keep[n] = (t >= gt_depth) */
 int nsk_inside_filter(nsk_ctx* ctx, int N, const float* d_rays_o, const float* d_rays_d, const float* d_gt_depth,
                       uint8_t* d_keep);
+/* The reference drops the rays that fail the test above before it renders them (boolean-index compaction, src/Mapper.cpp:423-427,
+ * src/Tracker.cpp:55-58), which needs their count on the host.  Here they stay in place and are neutralised instead: with a mask
+ * installed (d_keep [N] as written by nsk_inside_filter, device memory, must stay valid; NULL = none), nsk_map_step, nsk_track_step and
+ * nsk_render_backward leave the rays with d_keep == 0 out of max(gt_depth), the Tracker's median, the loss and every gradient --
+ * the same sums the reference forms over the compacted batch, with no device-to-host round trip. */
+int nsk_set_ray_mask(nsk_ctx* ctx, const uint8_t* d_keep);
 /* plain Adam on a caller-owned vector (camera 7-vectors: src/Tracker.cpp:103, src/Mapper.cpp:305-329) */
 int nsk_adam_vector(nsk_ctx* ctx, int n, float* d_p, const float* d_g, float* d_m, float* d_v, float lr, float beta1,
                     float beta2, float eps, int step);

@@ -200,11 +200,21 @@ __global__ void k_loss_track(int N, const float* depth, const float* rgb, const 
 }
 
 // 10 * torch.median(|gt - depth|) (lower median) by a single-workgroup bitonic sort in LDS
-__global__ __launch_bounds__(1024) void k_median_thr(int N, int P2, const float* gt_d, const float* depth, float* thr)
+__global__ __launch_bounds__(1024) void k_median_thr(int N, int P2, const float* gt_d, const float* depth, const uint8_t* keep, float* thr)
 {
     extern __shared__ float shm[];
-    for (int i = threadIdx.x; i < P2; i += 1024) shm[i] = i < N ? fabsf(gt_d[i] - depth[i]) : NSK_INF;
+    __shared__ int nvalid;
+    if (threadIdx.x == 0) nvalid = 0;
     __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < P2; i += 1024) {
+        const bool ok = i < N && (!keep || keep[i]);
+        shm[i] = ok ? fabsf(gt_d[i] - depth[i]) : NSK_INF;       // masked rays sort to the end
+        cnt += ok ? 1 : 0;
+    }
+    if (cnt) atomicAdd(&nvalid, cnt);
+    __syncthreads();
+    N = max(nvalid, 1);
     for (int k = 2; k <= P2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < P2; i += 1024) {
@@ -570,6 +580,7 @@ struct nsk_ctx {
     std::vector<GraphRec> graphs;
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
+    const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
     bool sorted = false;                    // the current step's decoder launches walk the samples in cell-sorted order (ws.perm)
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
@@ -712,6 +723,13 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
     return fail("nsk_set_tuning: unknown key '%s'", key);
+}
+
+extern "C" int nsk_set_ray_mask(nsk_ctx* c, const uint8_t* d_keep)
+{
+    if (!c) return fail("null ctx");
+    c->ray_mask = d_keep;
+    return 0;
 }
 
 extern "C" int nsk_set_sort_mode(nsk_ctx* c, int mode)
@@ -1309,6 +1327,7 @@ static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, co
                         bool sorted = false)
 {
     const int M = N * S;
+    const uint8_t* mask = save_masks ? c->ray_mask : nullptr;      // (only the steps that form a loss honour it; a plain render shows every ray)
     c->sorted = sorted;
     int key_level = 0;
     for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) key_level = STAGE_DEC[stage][q];      // the finest level the stage reads
@@ -1319,12 +1338,12 @@ static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, co
     const float* gmax_dev = nullptr;
     if (gt && gtmax < 0.f && N > 8192) {        // smaller batches: k_sample's waves take the maximum themselves
         ProfScope ps(c, "depth_max");
-        k_depth_max<<<1, 1024, 0, c->stream>>>(N, gt, c->scal);
+        k_depth_max<<<1, 1024, 0, c->stream>>>(N, gt, mask, c->scal);
         gmax_dev = c->scal;
     }
     {
     ProfScope ps(c, "sample");
-    k_sample<<<(N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS, 64 * NSK_SAMPLE_RAYS, 0, c->stream>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, c->ws.z, KG.X, KG.Y, KG.Z, PG ? PG->X : 0, PG ? PG->Y : 0, PG ? PG->Z : 0, (int)((bins / 8 + 1) / 2),
+    k_sample<<<(N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS, 64 * NSK_SAMPLE_RAYS, 0, c->stream>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, mask, c->ws.z, KG.X, KG.Y, KG.Z, PG ? PG->X : 0, PG ? PG->Y : 0, PG ? PG->Z : 0, (int)((bins / 8 + 1) / 2),
                                                  sorted ? c->ws.skey : nullptr, c->ws.srank, c->ws.hist);
     }
     if (sorted) {
@@ -1345,6 +1364,7 @@ static void comp_args(nsk_ctx* c, CompArgs& A, int stage, int N, int S, const fl
     A.occ_b = stage >= 2 ? c->ws.occ[2] : nullptr;
     A.rgb4 = stage == 3 ? c->ws.rgb4 : nullptr;
     A.g_raw = c->ws.g_raw;
+    A.keep = c->ray_mask;
 }
 
 static int common_checks(nsk_ctx* c, int stage, int N, const float* ro, const float* rd, int* S_out, const float* gt)
@@ -1535,7 +1555,7 @@ static int median_thr(nsk_ctx* c, int N, const float* gt, const float* depth)
 {
     int P2 = 1; while (P2 < N) P2 <<= 1;
     if (P2 > 16384) return fail("handle_dynamic median supports at most 16384 rays (got %d)", N);
-    k_median_thr<<<1, 1024, P2 * 4, c->stream>>>(N, P2, gt, depth, c->scal + 1);
+    k_median_thr<<<1, 1024, P2 * 4, c->stream>>>(N, P2, gt, depth, c->ray_mask, c->scal + 1);
     HIPCHK(hipGetLastError());
     return 0;
 }

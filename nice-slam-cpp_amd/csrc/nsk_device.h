@@ -87,11 +87,11 @@ __device__ __forceinline__ float wave_max(float v)
 // ------------------------------------------------------------------------------------------------------
 // K0: batch maximum of gt_depth (reference src/Renderer.cpp:76,93 torch::max(gt_depth)) -> *out
 // ------------------------------------------------------------------------------------------------------
-__global__ void k_depth_max(int N, const float* __restrict__ gt, float* __restrict__ out)
+__global__ void k_depth_max(int N, const float* __restrict__ gt, const uint8_t* __restrict__ keep, float* __restrict__ out)
 {
     __shared__ float sh[16];
     float m = -NSK_INF;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) m = fmaxf(m, gt[i]);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) if (!keep || keep[i]) m = fmaxf(m, gt[i]);
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -139,7 +139,7 @@ __device__ __forceinline__ int cell_index(int GX, int GY, int GZ, const float* b
 #define NSK_SAMPLE_TABLE 2048       // slots of its cell table (>= 2 x NSK_SAMPLE_RAYS x 64 keeps probing short)
 __global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int N, int S, const float* __restrict__ rays_o,
                                                 const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
-                                                float gtmax_host, const float* __restrict__ gtmax_dev,
+                                                float gtmax_host, const float* __restrict__ gtmax_dev, const uint8_t* __restrict__ keep,
                                                 float* __restrict__ z_out, int kX, int kY, int kZ, int pX, int pY, int pZ, int ncell2,
                                                 int* __restrict__ skey, int* __restrict__ srank, int* __restrict__ hist)
 {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int 
     float gmax = gtmax_dev ? *gtmax_dev : gtmax_host;
     if (has_gt && !gtmax_dev && gtmax_host < 0.f) {         // batch maximum computed by every wave itself (small batches: one launch fewer)
         float mx = -NSK_INF;
-        for (int i = lane; i < N; i += 64) mx = fmaxf(mx, gt_depth[i]);
+        for (int i = lane; i < N; i += 64) if (!keep || keep[i]) mx = fmaxf(mx, gt_depth[i]);
         gmax = wave_max(mx);
     }
     const float ox = rays_o[3 * nc], oy = rays_o[3 * nc + 1], oz = rays_o[3 * nc + 2];
@@ -847,6 +847,8 @@ struct CompArgs {
     float* loss;                                                              // modes 2,3: per-ray loss [N] or nullptr
     float* g_raw;                                                             // [M][4]
     float* g_rays_o; float* g_rays_d;                                         // [N][3] seeds or nullptr
+    const uint8_t* keep;                                                      // [N] or nullptr: rays with keep == 0 are rendered but take no part in
+                                                                              // the loss or its gradient (nsk_set_ray_mask: the reference drops them)
 };
 
 __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
@@ -902,7 +904,10 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
     if (A.mode == 0) return;
     // ---- seed gradients -------------------------------------------------------------------------------
     float gD = 0.f, gV = 0.f, gC[3] = {0.f, 0.f, 0.f};
-    if (A.mode == 1) {
+    const bool kept = !A.keep || A.keep[n];
+    if (!kept) {
+        if (A.loss && lane == 0) A.loss[n] = 0.f;
+    } else if (A.mode == 1) {
         gD = A.g_depth ? A.g_depth[n] : 0.f;
         gV = A.g_var ? A.g_var[n] : 0.f;
         gC[0] = A.g_rgb[3 * n]; gC[1] = A.g_rgb[3 * n + 1]; gC[2] = A.g_rgb[3 * n + 2];

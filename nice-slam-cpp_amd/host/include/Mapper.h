@@ -1,13 +1,13 @@
-// Same surface as the reference's include/Mapper.h:11-44 for the hot path: Mapper(), run(), optimize_map().
-// get_mask_from_c2w (next row N2) runs on the device (nsk_frustum_mask) when mapping.frustum_feature_selection is set, except on
-// levels where the caller installed its own mask with set_frustum_mask.  keyframe_selection_overlap (next row N3) is folded into optimize_map too:
-// the per-keyframe overlap fractions come from nsk_keyframe_overlap, the ranking stays on the host.
+// Same surface as the reference's include/Mapper.h:4-44: Mapper(), run(), optimize_map(), keyframe_selection_overlap(),
+// get_mask_from_c2w().  The last two are thin methods over nsk_keyframe_overlap / nsk_frustum_mask (next rows N3 / N2); optimize_map
+// calls the same entry points itself, except on levels where the caller installed its own mask with set_frustum_mask.
 #pragma once
-#include <algorithm>
 #include <iostream>
 #include <memory>
+#include "inputs/CoFusionReader.h"
 #include <yaml-cpp/yaml.h>
 #include "Renderer.h"
+#include <algorithm>
 
 struct KeyFrame {
     torch::Tensor cur_c2w, est_c2w, gt_c2w, gt_color, gt_depth, color, depth;
@@ -22,6 +22,12 @@ class Mapper {
              torch::Tensor gt_depth_t, torch::Tensor gt_c2w_t, int idx, int n_imgs);
     void optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Tensor>& c_dict, torch::Tensor cur_gt_color, torch::Tensor cur_gt_depth,
                       torch::Tensor gt_cur_c2w, torch::Tensor& cur_c2w, NICE& decoders);
+    // src/Mapper.cpp:132-196: indices (into keyframe_vector_) of the k_overlap keyframes that see most of the current frame's samples
+    void keyframe_selection_overlap(torch::Tensor gt_color_, torch::Tensor gt_depth_, torch::Tensor c2w, std::vector<KeyFrame> keyframe_vector_, int k_overlap,
+                                    std::vector<int>& selected_kf);
+    // src/Mapper.cpp:42-130: frustum mask of the level `key` ("grid_coarse" ...) for a depth image and pose; val_shape = (Z, Y, X) of the
+    // level as the reference passes it (:258); mask comes back bool [X, Y, Z] like the reference's (its caller permutes it to Z,Y,X)
+    void get_mask_from_c2w(cv::Mat depth_mat, torch::Tensor c2w, torch::Tensor val_shape, std::string key, torch::Tensor& mask);
     // not in the reference
     void set_frustum_mask(const std::string& grid_key, torch::Tensor mask_zyx);     // bool/uint8 [Z,Y,X]; undefined tensor = all
     void set_bound(torch::Tensor bound_3x2);
@@ -30,6 +36,9 @@ class Mapper {
     float last_loss = 0.f;
     std::vector<float> last_overlap;       // overlap fraction of keyframes [0, n-1) in that call (empty if not ranked)
     std::vector<int> last_window;          // keyframe indices of the last optimize_map call (-1 = current frame)
+    double last_iter_us = 0.0;             // mean wall time of one iteration of the last optimize_map loop (stream-synchronised at its end)
+    bool render_stage_literal_color = true;   // src/Mapper.cpp:430 renders the literal "color" whatever the stage (D19, reproduced by default);
+                                              // false = render `stage`, the intended graph
 
   private:
     Renderer renderer;
@@ -51,4 +60,6 @@ class Mapper {
     bool first_frame = true;
     bool user_mask[4] = {false, false, false, false};
     uint64_t rng_seed = 0;
+    struct Dev;                            // device-resident state of optimize_map: frame images, ray buffers, BA poses and their Adam moments
+    std::shared_ptr<Dev> dev;
 };

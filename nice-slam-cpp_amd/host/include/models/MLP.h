@@ -5,6 +5,7 @@
 #include <map>
 #include <torch/torch.h>
 #include "models/GaussianFFT.h"
+#include "torchlib/utils.h"      // as the reference's include/models/MLP.h:3 does: src/main.cpp relies on its `using namespace torch::indexing`
 
 struct MLP : torch::nn::Module {
     MLP(std::string name, int dim, int c_dim, int hidden_size, int n_blocks, bool color, std::vector<int> skips, float grid_len,

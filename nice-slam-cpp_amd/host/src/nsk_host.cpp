@@ -4,6 +4,7 @@
 // Each function cites the reference code whose behaviour it reproduces (intended semantics).
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -420,8 +421,86 @@ static torch::Tensor inside_mask(const torch::Tensor& bound, const torch::Tensor
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// device-resident state shared by Tracker::run and Mapper::optimize_map
+// ---------------------------------------------------------------------------------------------------------
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+namespace {
+
+// grow-only device array; uploads and downloads go through the kernels' stream, so they are ordered with the launches
+template <typename T>
+struct DevArr {
+    T* p = nullptr; size_t cap = 0;
+    ~DevArr() { if (p) hipFree(p); }
+    DevArr() {}
+    DevArr(const DevArr&) = delete;
+    DevArr& operator=(const DevArr&) = delete;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        check(nsk_sync(ctx()));                          // nobody may still be reading the old buffer
+        if (p) HIPOK(hipFree(p));
+        HIPOK(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+    }
+    void upload(const T* h, size_t n)
+    {
+        ensure(n);
+        HIPOK(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, (hipStream_t)nsk_stream(ctx())));
+        check(nsk_sync(ctx()));                          // h may be a temporary
+    }
+    void zero(size_t n) { ensure(n); HIPOK(hipMemsetAsync(p, 0, n * sizeof(T), (hipStream_t)nsk_stream(ctx()))); }
+    void download(T* h, size_t n) const
+    {
+        HIPOK(hipMemcpyAsync(h, p, n * sizeof(T), hipMemcpyDeviceToHost, (hipStream_t)nsk_stream(ctx())));
+        check(nsk_sync(ctx()));
+    }
+};
+
+// one frame's images on the device, keyed by the host tensors they came from (a keyframe is uploaded once, not once per iteration)
+struct DevFrame {
+    DevArr<float> depth, color;
+    const void* key_d = nullptr; const void* key_c = nullptr; int64_t ver_d = -1, ver_c = -1;
+    int H = 0, W = 0;
+    void set(const torch::Tensor& depth_t, const torch::Tensor& color_t)
+    {
+        if (depth_t.data_ptr() == key_d && (int64_t)depth_t._version() == ver_d && color_t.data_ptr() == key_c && (int64_t)color_t._version() == ver_c) return;
+        torch::Tensor d = depth_t.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+        torch::Tensor c = color_t.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+        TORCH_CHECK(d.dim() == 2 && c.dim() == 3 && c.size(2) == 3 && c.size(0) == d.size(0) && c.size(1) == d.size(1), "frame images must be depth [H,W] and colour [H,W,3]");
+        H = (int)d.size(0); W = (int)d.size(1);
+        depth.upload(d.data_ptr<float>(), (size_t)d.numel());
+        color.upload(c.data_ptr<float>(), (size_t)c.numel());
+        key_d = depth_t.data_ptr(); ver_d = (int64_t)depth_t._version(); key_c = color_t.data_ptr(); ver_c = (int64_t)color_t._version();
+    }
+};
+
+struct RayBufs {                 // one batch of rays on the device
+    DevArr<int32_t> pi, pj;
+    DevArr<float> ro, rd, gd, gc, g_ro, g_rd;
+    DevArr<uint8_t> keep;
+    void ensure(size_t n)
+    {
+        pi.ensure(n); pj.ensure(n); ro.ensure(3 * n); rd.ensure(3 * n); gd.ensure(n); gc.ensure(3 * n); g_ro.ensure(3 * n); g_rd.ensure(3 * n); keep.ensure(n);
+    }
+};
+
+double now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
 // Tracker
 // ---------------------------------------------------------------------------------------------------------
+struct Tracker::Dev {
+    DevFrame frame;
+    RayBufs rays;
+    DevArr<float> cam, m, v, losses;     // pose 7-vector, its Adam moments, one loss per iteration
+};
+
 Tracker::Tracker(YAML::Node ns_config, YAML::Node cf_config, c10::Dict<std::string, torch::Tensor> c_dict) : renderer()      // Tracker.cpp:5-34
 {
     handle_dynamic = ns_config["tracking"]["handle_dynamic"].as<bool>();
@@ -438,64 +517,119 @@ Tracker::Tracker(YAML::Node ns_config, YAML::Node cf_config, c10::Dict<std::stri
     cx = cf_config["cam"]["cx"].as<float>(); cy = cf_config["cam"]["cy"].as<float>();
     idx = 0;
     c = c_dict;
+    dev = std::make_shared<Dev>();
 }
 Tracker::~Tracker() {}
 void Tracker::update_para_from_mapping() {}
 void Tracker::set_bound(torch::Tensor b) { bound = b.detach().to(torch::kCPU, torch::kFloat32).clone(); renderer.set_bound(bound); }
 
+// One iteration through the public signature (the reference's: cam tensor and torch optimiser on the host).  The batch lives on the
+// device (pixel draw, gather, rays, bound filter, render, loss, backward, d loss / d pose); only the 7 pose gradients and the loss come
+// back, because the caller's torch::optim::Adam owns the step.  Tracker::run keeps the pose and its Adam state on the device as well.
 torch::Tensor Tracker::optimize_cam_in_batch(torch::Tensor cam_tensor, torch::Tensor gt_color, torch::Tensor gt_depth, int batch_size,
                                              torch::optim::Adam& optimizer, NICE decoders)      // Tracker.cpp:41-89
 {
     optimizer.zero_grad();
+    Dev& D = *dev;
+    D.frame.set(gt_depth, gt_color);
     torch::Tensor cam_cpu = cam_tensor.detach().to(torch::kCPU, torch::kFloat32).contiguous();
-    torch::Tensor c2w = get_camera_from_tensor(cam_cpu);
-    torch::Tensor ro, rd, gd, gc, pi, pj;
-    get_samples(ignore_edge_h, H - ignore_edge_h, ignore_edge_w, W - ignore_edge_w, batch_size, H, W, fx, fy, cx, cy, c2w, gt_depth, gt_color,
-                ro, rd, gd, gc, &pi, &pj);
-    torch::Tensor keep = inside_mask(bound, ro, rd, gd);                                      // :48-58 (detached, D7)
-    ro = ro.index({keep}).contiguous(); rd = rd.index({keep}).contiguous(); gd = gd.index({keep}).contiguous();
-    gc = gc.index({keep}).contiguous(); pi = pi.index({keep}).contiguous(); pj = pj.index({keep}).contiguous();
-    const int N = (int)ro.size(0);
-    TORCH_CHECK(N > 0, "optimize_cam_in_batch: every sampled ray was rejected by the bound test");
-    // render + loss + backward onto the rays in the kernels, then the pose chain (rays -> c2w -> quaternion/translation)
+    D.cam.upload(cam_cpu.data_ptr<float>(), 7);
+    const int N = batch_size;
+    D.rays.ensure((size_t)N); D.losses.ensure(4); D.m.ensure(16);
     nskh::set_bound_ctx(bound);
     check(nsk_set_render_opts(ctx(), renderer.N_samples, renderer.N_surface, renderer.lindisp, renderer.perturb, renderer.occupancy, 0));
     nskh::sync_grids(c);
     decoders.sync_to_device();
-    DevBuf d_ro, d_rd, d_gd, d_gc, d_gro, d_grd, d_loss, d_cam, d_gc2w, d_gcam, d_pi, d_pj;
-    d_ro.upload(ro); d_rd.upload(rd); d_gd.upload(gd); d_gc.upload(gc); d_cam.upload(cam_cpu);
-    d_gro.ensure((size_t)N * 3); d_grd.ensure((size_t)N * 3); d_loss.ensure(4); d_gc2w.ensure(12); d_gcam.ensure(8);
-    d_pi.ensure(N); d_pj.ensure(N);      // int32 payloads in float-sized slots
-    hipMemcpy(d_pi.p, pi.data_ptr<int32_t>(), N * sizeof(int32_t), hipMemcpyHostToDevice);
-    hipMemcpy(d_pj.p, pj.data_ptr<int32_t>(), N * sizeof(int32_t), hipMemcpyHostToDevice);
-    check(nsk_track_step(ctx(), NSK_COLOR, N, d_ro.p, d_rd.p, d_gd.p, d_gc.p, -1.f, w_color_loss, use_color_in_tracking ? 1 : 0,
-                         handle_dynamic ? 1 : 0, 1, NSK_GRAD_RAYS, d_loss.p, d_gro.p, d_grd.p));      // stage "color": :61 (D19)
-    check(nsk_rays_backward(ctx(), N, (const int32_t*)d_pi.p, (const int32_t*)d_pj.p, fx, fy, cx, cy, 0, d_gro.p, d_grd.p, d_gc2w.p));
-    check(nsk_camera_backward(ctx(), d_cam.p, d_gc2w.p, d_gcam.p));
-    torch::Tensor g = d_gcam.download({8}).index({Slice(None, 7)}).clone();
-    torch::Tensor loss = d_loss.download({4}).index({0}).clone();
-    cam_tensor.mutable_grad() = g.to(cam_tensor.device());                                    // loss.backward() :84
-    optimizer.step();                                                                         // :85
+    RayBufs& R = D.rays;
+    check(nsk_sample_pixels(ctx(), rng_seed++, N, ignore_edge_h, H - ignore_edge_h, ignore_edge_w, W - ignore_edge_w, R.pi.p, R.pj.p));      // utils.h:19-36
+    check(nsk_gather_pixels(ctx(), N, R.pi.p, R.pj.p, D.frame.H, D.frame.W, D.frame.depth.p, D.frame.color.p, R.gd.p, R.gc.p));               // :38-43
+    check(nsk_rays_from_camera(ctx(), N, R.pi.p, R.pj.p, fx, fy, cx, cy, D.cam.p, 0, R.ro.p, R.rd.p, nullptr));                              // :44-52 + utils.h:198
+    check(nsk_inside_filter(ctx(), N, R.ro.p, R.rd.p, R.gd.p, R.keep.p));                                                                    // Tracker.cpp:48-58
+    check(nsk_set_ray_mask(ctx(), R.keep.p));
+    check(nsk_track_step(ctx(), NSK_COLOR, N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, use_color_in_tracking ? 1 : 0,
+                         handle_dynamic ? 1 : 0, 1, NSK_GRAD_RAYS, D.losses.p, R.g_ro.p, R.g_rd.p));      // stage "color": :61 (D19)
+    check(nsk_set_ray_mask(ctx(), nullptr));
+    float* g_c2w = D.m.p;              // 12 floats of scratch
+    check(nsk_rays_backward(ctx(), N, R.pi.p, R.pj.p, fx, fy, cx, cy, 0, R.g_ro.p, R.g_rd.p, g_c2w));
+    check(nsk_camera_backward(ctx(), D.cam.p, g_c2w, D.losses.p + 1));          // losses[1..7] = d loss / d pose
+    float h[8];
+    D.losses.ensure(8);
+    D.losses.download(h, 8);
+    cam_tensor.mutable_grad() = torch::from_blob(h + 1, {7}, torch::kFloat32).clone().to(cam_tensor.device());       // loss.backward() :84
+    optimizer.step();                                                                                              // :85
     optimizer.zero_grad();
-    return loss;
+    return torch::tensor(h[0]);
 }
 
 void Tracker::run(NICE decoders, torch::Tensor gt_color_t, torch::Tensor gt_depth_t, torch::Tensor gt_c2w_t, int idx_)       // Tracker.cpp:92-113
 {
     idx = idx_;
-    torch::Tensor camera_tensor = get_tensor_from_camera(gt_c2w_t, false).requires_grad_(true);   // :100 (initialised from the GT pose, D25)
-    std::vector<torch::Tensor> cam_para_list{camera_tensor};
-    torch::optim::Adam optimizer(cam_para_list, torch::optim::AdamOptions(lr));               // config tracking.lr (D25)
-    for (int i = 0; i < num_cam_iters; ++i) {
-        auto loss = optimize_cam_in_batch(camera_tensor, gt_color_t, gt_depth_t, tracking_pixels, optimizer, decoders);
-        std::cout << "loss: " << loss.item<float>() << std::endl;                             // :111
+    Dev& D = *dev;
+    torch::Tensor cam0 = get_tensor_from_camera(gt_c2w_t, false).contiguous();      // :100 (initialised from the GT pose, D25)
+    D.frame.set(gt_depth_t, gt_color_t);
+    D.cam.upload(cam0.data_ptr<float>(), 7);
+    D.m.zero(16); D.v.zero(16);                                                       // torch::optim::Adam re-created per frame (:103)
+    const int N = tracking_pixels, iters = num_cam_iters;
+    D.rays.ensure((size_t)N); D.losses.ensure((size_t)std::max(iters, 8));
+    nskh::set_bound_ctx(bound);
+    check(nsk_set_render_opts(ctx(), renderer.N_samples, renderer.N_surface, renderer.lindisp, renderer.perturb, renderer.occupancy, 0));
+    nskh::sync_grids(c);
+    decoders.sync_to_device();
+    RayBufs& R = D.rays;
+    check(nsk_sync(ctx()));
+    const double t0 = now_us();
+    for (int i = 0; i < iters; ++i) {                                                 // :108-112, every operand resident on the device
+        check(nsk_sample_pixels(ctx(), rng_seed++, N, ignore_edge_h, H - ignore_edge_h, ignore_edge_w, W - ignore_edge_w, R.pi.p, R.pj.p));
+        check(nsk_gather_pixels(ctx(), N, R.pi.p, R.pj.p, D.frame.H, D.frame.W, D.frame.depth.p, D.frame.color.p, R.gd.p, R.gc.p));
+        check(nsk_rays_from_camera(ctx(), N, R.pi.p, R.pj.p, fx, fy, cx, cy, D.cam.p, 0, R.ro.p, R.rd.p, nullptr));
+        check(nsk_inside_filter(ctx(), N, R.ro.p, R.rd.p, R.gd.p, R.keep.p));
+        check(nsk_set_ray_mask(ctx(), R.keep.p));
+        check(nsk_track_step(ctx(), NSK_COLOR, N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, use_color_in_tracking ? 1 : 0,
+                             handle_dynamic ? 1 : 0, 1, NSK_GRAD_RAYS, D.losses.p + i, R.g_ro.p, R.g_rd.p));
+        check(nsk_set_ray_mask(ctx(), nullptr));
+        check(nsk_pose_step(ctx(), N, R.pi.p, R.pj.p, fx, fy, cx, cy, 0, R.g_ro.p, R.g_rd.p, D.cam.p, D.m.p, D.v.p, lr, 0.9f, 0.999f, 1e-8f, i + 1, nullptr));   // config tracking.lr (D25)
     }
-    last_camera_tensor = camera_tensor.detach().clone();
+    check(nsk_sync(ctx()));
+    last_run_us = now_us() - t0;
+    last_losses.assign((size_t)iters, 0.f);
+    if (iters > 0) D.losses.download(last_losses.data(), (size_t)iters);              // the only device-to-host traffic of the frame: losses and pose
+    for (float l : last_losses) std::cout << "loss: " << l << std::endl;              // :111
+    float h[7];
+    D.cam.download(h, 7);
+    last_camera_tensor = torch::from_blob(h, {7}, torch::kFloat32).clone();
+}
+
+void Tracker::run(CoFusionReader& reader, NICE decoders)                              // src/main.cpp:96 (D1)
+{
+    int n = 0;
+    while (reader.hasMore() && (frames_limit < 0 || n < frames_limit)) {
+        const int frame = reader.getIdx();
+        reader.getNext();
+        // cv::Mat -> tensors: depth [H,W] fp32, colour [H,W,3] fp32; the dataset has no poses: c2w = the reader's identity (CoFusionReader.cpp:14)
+        torch::Tensor depth_t = torch::from_blob(reader.depth.data, {reader.depth.rows, reader.depth.cols}, torch::kFloat32).clone();
+        torch::Tensor color_t = torch::from_blob(reader.rgb.data, {reader.rgb.rows, reader.rgb.cols, reader.rgb.channels()}, torch::kFloat32).clone();
+        if (color_t.size(2) > 3) color_t = color_t.index({Slice(), Slice(), Slice(None, 3)}).contiguous();
+        torch::Tensor c2w_t = torch::zeros({4, 4});
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c2w_t[i][j] = reader.c2w(i, j);
+        run(decoders, color_t, depth_t, c2w_t, frame);
+        ++n;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Mapper
 // ---------------------------------------------------------------------------------------------------------
+struct Mapper::Dev {
+    DevFrame cur;                                        // current frame
+    std::vector<std::shared_ptr<DevFrame>> kf;           // keyframes, index = position in keyframe_vector
+    RayBufs rays;
+    DevArr<float> poses;                                 // [frames of the window][12] fixed c2w rows (3x4)
+    DevArr<float> cams, cam_m, cam_v;                    // BA: [frames][8] pose 7-vectors and their Adam moments
+    DevArr<float> loss;
+    DevArr<float> kf_ro, kf_rd, kf_gd;                   // the 100 overlap-ranking rays
+    DevArr<int32_t> kf_pi, kf_pj;
+};
+
 Mapper::Mapper(YAML::Node ns_config, YAML::Node cf_config, bool cmapr) : renderer()           // Mapper.cpp:6-36
 {
     ns_cfg = ns_config; cf_cfg = cf_config;
@@ -519,66 +653,109 @@ Mapper::Mapper(YAML::Node ns_config, YAML::Node cf_config, bool cmapr) : rendere
     lr_factor = ns_cfg["mapping"]["lr_first_factor"].as<float>();
     BA_cam_lr = ns_cfg["mapping"]["BA_cam_lr"].as<float>();
     w_color_loss = ns_cfg["tracking"]["w_color_loss"].as<float>();                           // :33 as written (D20)
+    dev = std::make_shared<Dev>();
 }
 Mapper::~Mapper() {}
 void Mapper::set_bound(torch::Tensor b) { bound = b.detach().to(torch::kCPU, torch::kFloat32).clone(); renderer.set_bound(bound); }
 
-void Mapper::set_frustum_mask(const std::string& key, torch::Tensor mask)
+static int level_of_key(const std::string& key)
 {
     int level = key == "grid_coarse" ? 0 : key == "grid_middle" ? 1 : key == "grid_fine" ? 2 : key == "grid_color" ? 3 : -1;
     TORCH_CHECK(level >= 0, "unknown grid key ", key);
+    return level;
+}
+
+void Mapper::set_frustum_mask(const std::string& key, torch::Tensor mask)
+{
+    const int level = level_of_key(key);
     user_mask[level] = true;
     if (!mask.defined()) { check(nsk_set_mask(ctx(), level, nullptr)); return; }
     torch::Tensor m = mask.to(torch::kCPU, torch::kUInt8).contiguous();
     check(nsk_set_mask(ctx(), level, m.data_ptr<uint8_t>()));
 }
 
+void Mapper::get_mask_from_c2w(cv::Mat depth_mat, torch::Tensor c2w, torch::Tensor val_shape, std::string key, torch::Tensor& mask)      // Mapper.cpp:42-130
+{
+    const int level = level_of_key(key);
+    TORCH_CHECK(depth_mat.type() == CV_32FC1, "get_mask_from_c2w: depth must be CV_32FC1");
+    torch::Tensor vs = val_shape.to(torch::kCPU, torch::kInt64).contiguous();
+    const int64_t Z = vs[0].item<int64_t>(), Y = vs[1].item<int64_t>(), X = vs[2].item<int64_t>();
+    nskh::set_bound_ctx(bound);
+    torch::Tensor pose = c2w.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+    TORCH_CHECK(pose.numel() == 16, "get_mask_from_c2w: c2w must be 4x4");
+    DevArr<float> img;
+    img.upload(depth_mat.ptr<float>(), depth_mat.total());
+    torch::Tensor out = torch::zeros({Z, Y, X}, torch::kUInt8);
+    check(nsk_frustum_mask(ctx(), level, img.p, depth_mat.rows, depth_mat.cols, fx, fy, cx, cy, pose.data_ptr<float>(), out.data_ptr<uint8_t>()));
+    mask = out.to(torch::kBool).permute({2, 1, 0}).contiguous();          // [X,Y,Z], the layout the reference's caller permutes back (:260)
+}
+
+void Mapper::keyframe_selection_overlap(torch::Tensor gt_color_, torch::Tensor gt_depth_, torch::Tensor c2w, std::vector<KeyFrame> keyframe_vector_, int k_overlap,
+                                        std::vector<int>& selected_kf)                                                          // Mapper.cpp:132-196
+{
+    selected_kf.clear();
+    last_overlap.clear();
+    const int K = (int)keyframe_vector_.size();
+    if (K == 0) return;
+    Dev& D = *dev;
+    const int n = 100, ns = 16;                                                               // :136
+    D.cur.set(gt_depth_, gt_color_);
+    D.kf_pi.ensure(n); D.kf_pj.ensure(n); D.kf_ro.ensure(3 * n); D.kf_rd.ensure(3 * n); D.kf_gd.ensure(n);
+    torch::Tensor pose = c2w.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+    D.poses.upload(pose.data_ptr<float>(), 12);
+    check(nsk_sample_pixels(ctx(), rng_seed + 0x9e3779b9ull * (uint64_t)(K + 1), n, 0, H, 0, W, D.kf_pi.p, D.kf_pj.p));        // get_samples(0,H,0,W,100,...) :137
+    check(nsk_gather_pixels(ctx(), n, D.kf_pi.p, D.kf_pj.p, D.cur.H, D.cur.W, D.cur.depth.p, nullptr, D.kf_gd.p, nullptr));
+    check(nsk_rays_from_pixels(ctx(), n, D.kf_pi.p, D.kf_pj.p, fx, fy, cx, cy, D.poses.p, 0, D.kf_ro.p, D.kf_rd.p));
+    std::vector<float> poses((size_t)K * 16), pct((size_t)K);
+    for (int k = 0; k < K; ++k) {
+        torch::Tensor m = keyframe_vector_[k].est_c2w.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+        std::memcpy(poses.data() + 16 * k, m.data_ptr<float>(), 16 * sizeof(float));
+    }
+    check(nsk_keyframe_overlap(ctx(), n, D.kf_ro.p, D.kf_rd.p, D.kf_gd.p, ns, H, W, fx, fy, cx, cy, K, poses.data(), pct.data()));
+    std::vector<int> order;
+    for (int k = 0; k < K; ++k) if (pct[k] > 0.f) order.push_back(k);                         // :178-179
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pct[a] > pct[b]; });   // :186-190
+    if ((int)order.size() > std::max(0, k_overlap)) order.resize((size_t)std::max(0, k_overlap));  // :194-195 (size_t underflow read as intended)
+    selected_kf = order;
+    last_overlap = pct;
+}
+
 void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Tensor>& c, torch::Tensor cur_gt_color, torch::Tensor cur_gt_depth,
                           torch::Tensor gt_cur_c2w, torch::Tensor& cur_c2w, NICE& decoders)     // Mapper.cpp:198-491
 {
     (void)gt_cur_c2w;
-    // window (:200-216): the mapping_window_size-2 keyframes that overlap the current frame most (keyframe_selection_overlap,
-    // :132-196, over all keyframes but the last as in the original's keyframe_dict[:-1]), the last keyframe, the current frame (-1)
+    Dev& D = *dev;
+    // window (:200-216): the mapping_window_size-2 keyframes that overlap the current frame most (over all keyframes but the last, as in
+    // the original's keyframe_dict[:-1]), the last keyframe, the current frame (-1)
     std::vector<int> optimize_frame;
     const int nkf = (int)keyframe_vector.size();
     if (nkf > 1 && keyframe_selection_method == "overlap") {
-        torch::Tensor ro, rd, gd, gc;
-        get_samples(0, H, 0, W, 100, H, W, fx, fy, cx, cy, cur_c2w, cur_gt_depth, cur_gt_color, ro, rd, gd, gc);     // :137
-        DevBuf d_ro, d_rd, d_gd;
-        d_ro.upload(ro); d_rd.upload(rd); d_gd.upload(gd);
-        std::vector<float> poses((size_t)(nkf - 1) * 16), pct(nkf - 1);
-        for (int k = 0; k < nkf - 1; ++k) {
-            torch::Tensor m = keyframe_vector[k].est_c2w.detach().to(torch::kCPU, torch::kFloat32).contiguous();
-            std::memcpy(poses.data() + 16 * k, m.data_ptr<float>(), 16 * sizeof(float));
-        }
-        check(nsk_keyframe_overlap(ctx(), (int)ro.size(0), d_ro.p, d_rd.p, d_gd.p, 16, H, W, fx, fy, cx, cy, nkf - 1, poses.data(), pct.data()));
-        std::vector<int> order;
-        for (int k = 0; k < nkf - 1; ++k) if (pct[k] > 0.f) order.push_back(k);                                     // :178-179
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pct[a] > pct[b]; });                  // :186-190
-        const int num = std::max(0, mapping_window_size - 2);
-        if ((int)order.size() > num) order.resize(num);                                                             // :194-195 (size_t underflow read as intended)
-        optimize_frame = order;
-        last_overlap = pct;
+        std::vector<KeyFrame> but_last(keyframe_vector.begin(), keyframe_vector.end() - 1);
+        keyframe_selection_overlap(cur_gt_color, cur_gt_depth, cur_c2w, but_last, mapping_window_size - 2, optimize_frame);
     } else {
         for (int k = std::max(0, nkf - (mapping_window_size - 1)); k < nkf - 1; ++k) optimize_frame.push_back(k);
     }
     if (nkf > 0) optimize_frame.push_back(nkf - 1);                                           // :211
-    int oldest_frame = optimize_frame.empty() ? -1 : *std::min_element(optimize_frame.begin(), optimize_frame.end());
+    const int oldest_frame = optimize_frame.empty() ? -1 : *std::min_element(optimize_frame.begin(), optimize_frame.end());
     optimize_frame.push_back(-1);                                                             // :216
     last_window = optimize_frame;
-    const int pixs_per_image = mapping_pixels / (int)optimize_frame.size();                   // :223 (D30)
+    const int nf = (int)optimize_frame.size();
+    const int pixs_per_image = mapping_pixels / nf;                                           // :223 (D30)
+    const int N = pixs_per_image * nf;
+    if (N == 0 || num_joint_iters_ <= 0) return;
 
     nskh::set_bound_ctx(bound);
     check(nsk_set_render_opts(ctx(), renderer.N_samples, renderer.N_surface, renderer.lindisp, renderer.perturb, renderer.occupancy, 0));
     nskh::sync_grids(c);
     decoders.sync_to_device();
+    // frame images: the current frame and every keyframe of the window, resident on the device (uploaded when first seen)
+    D.cur.set(cur_gt_depth, cur_gt_color);
+    if ((int)D.kf.size() < nkf) D.kf.resize((size_t)nkf);
+    for (int f : optimize_frame) if (f >= 0) { if (!D.kf[f]) D.kf[f] = std::make_shared<DevFrame>(); D.kf[f]->set(keyframe_vector[f].depth, keyframe_vector[f].color); }
     if (frustum_feature_selection) {                                            // :231-281 (depth_mat = cur_gt_depth intended, D21)
-        torch::Tensor dimg = cur_gt_depth.detach().to(torch::kCPU, torch::kFloat32).contiguous();
         torch::Tensor pose = cur_c2w.detach().to(torch::kCPU, torch::kFloat32).contiguous();
-        DevBuf d_img; d_img.upload(dimg);
         for (int level = 0; level < 4; ++level)
-            if (!user_mask[level]) check(nsk_frustum_mask(ctx(), level, d_img.p, (int)dimg.size(0), (int)dimg.size(1), fx, fy, cx, cy, pose.data_ptr<float>(), nullptr));
-        check(nsk_sync(ctx()));
+            if (!user_mask[level]) check(nsk_frustum_mask(ctx(), level, D.cur.depth.p, D.cur.H, D.cur.W, fx, fy, cx, cy, pose.data_ptr<float>(), nullptr));
     } else {
         for (int level = 0; level < 4; ++level) if (!user_mask[level]) check(nsk_set_mask(ctx(), level, nullptr));
     }
@@ -587,20 +764,28 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     check(nsk_adam_reset(ctx()));                                                             // the optimiser is re-created per call (:330)
     check(nsk_zero_grads(ctx()));
 
-    // bundle adjustment: one 7-vector per window frame except the oldest (:305-329), optimised on the host (7 parameters each)
-    std::vector<torch::Tensor> camera_tensor_list;
-    if (BA) {
-        for (int frame : optimize_frame) {
-            if (frame == oldest_frame) continue;
-            torch::Tensor c2w = frame != -1 ? keyframe_vector[frame].est_c2w : cur_c2w;
-            camera_tensor_list.push_back(get_tensor_from_camera(c2w, false).requires_grad_(true));
+    // poses of the window's frames: fixed ones as 3x4 rows, BA ones (every frame but the oldest, :305-329) as 7-vectors with Adam moments
+    std::vector<float> h_pose((size_t)nf * 12), h_cam((size_t)nf * 8, 0.f);
+    std::vector<int> is_ba((size_t)nf, 0);
+    for (int i = 0; i < nf; ++i) {
+        const int f = optimize_frame[i];
+        torch::Tensor c2w = (f != -1 ? keyframe_vector[f].est_c2w : cur_c2w).detach().to(torch::kCPU, torch::kFloat32).contiguous();
+        std::memcpy(h_pose.data() + 12 * i, c2w.data_ptr<float>(), 12 * sizeof(float));
+        if (BA && f != oldest_frame) {
+            is_ba[i] = 1;
+            torch::Tensor cam = get_tensor_from_camera(c2w, false).contiguous();
+            std::memcpy(h_cam.data() + 8 * i, cam.data_ptr<float>(), 7 * sizeof(float));
         }
     }
-    std::unique_ptr<torch::optim::Adam> cam_opt;
-    if (BA && !camera_tensor_list.empty()) cam_opt.reset(new torch::optim::Adam(camera_tensor_list, torch::optim::AdamOptions(0.0)));
-
-    DevBuf d_ro, d_rd, d_gd, d_gc, d_gro, d_grd, d_loss;
-    d_loss.ensure(4);
+    D.poses.upload(h_pose.data(), h_pose.size());
+    D.cams.upload(h_cam.data(), h_cam.size());
+    D.cam_m.zero((size_t)nf * 8); D.cam_v.zero((size_t)nf * 8);
+    D.rays.ensure((size_t)N); D.loss.ensure(4);
+    RayBufs& R = D.rays;
+    const bool any_ba = BA && std::count(is_ba.begin(), is_ba.end(), 1) > 0;
+    int ba_step = 0;
+    check(nsk_sync(ctx()));
+    const double t0 = now_us();
     for (int joint_iter = 0; joint_iter < num_joint_iters_; ++joint_iter) {
         if (coarse_mapper) stage = "coarse";                                                  // :351-358 (D18 intended)
         else if (joint_iter <= int(num_joint_iters_ * middle_iter_ratio)) stage = "middle";
@@ -614,70 +799,50 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
         lr[NSK_GROUP_FINE] = st["fine_lr"].as<float>() * lr_factor;
         lr[NSK_GROUP_COLOR] = st["color_lr"].as<float>() * lr_factor;
         lr[NSK_GROUP_CAMERA] = 0.f;
-        const bool ba_now = cam_opt && stage == "color";                                      // :366-368
-        if (cam_opt) {
-            static_cast<torch::optim::AdamOptions&>(cam_opt->param_groups()[0].options()).lr(ba_now ? BA_cam_lr : 0.0);
-            cam_opt->zero_grad();
+        const bool ba_now = any_ba && stage == "color";                                       // :366-368
+        // rays of every window frame (:376-414): pixel draw, ground-truth gather and ray generation on the device
+        for (int i = 0; i < nf; ++i) {
+            const int f = optimize_frame[i];
+            const DevFrame& F = f >= 0 ? *D.kf[f] : D.cur;
+            const size_t o = (size_t)i * pixs_per_image;
+            check(nsk_sample_pixels(ctx(), rng_seed + 0x100000001b3ull * (uint64_t)(joint_iter * nf + i + 1), pixs_per_image, 0, H, 0, W, R.pi.p + o, R.pj.p + o));
+            check(nsk_gather_pixels(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, F.H, F.W, F.depth.p, F.color.p, R.gd.p + o, R.gc.p + 3 * o));
+            if (is_ba[i]) check(nsk_rays_from_camera(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, fx, fy, cx, cy, D.cams.p + 8 * i, 0, R.ro.p + 3 * o, R.rd.p + 3 * o, nullptr));
+            else check(nsk_rays_from_pixels(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, fx, fy, cx, cy, D.poses.p + 12 * i, 0, R.ro.p + 3 * o, R.rd.p + 3 * o));
         }
-        // rays of every window frame (:376-414), sampled on the host like the reference does
-        std::vector<torch::Tensor> v_ro, v_rd, v_gd, v_gc, v_pi, v_pj;
-        std::vector<int> v_cam;      // camera tensor index per frame, -1 = fixed pose
-        int camera_tensor_id = 0;
-        for (int frame : optimize_frame) {
-            torch::Tensor gt_depth = frame != -1 ? keyframe_vector[frame].depth : cur_gt_depth;
-            torch::Tensor gt_color = frame != -1 ? keyframe_vector[frame].color : cur_gt_color;
-            torch::Tensor c2w; int cam_id = -1;
-            if (BA && frame != oldest_frame) { cam_id = camera_tensor_id++; c2w = get_camera_from_tensor(camera_tensor_list[cam_id].detach()); }
-            else c2w = frame != -1 ? keyframe_vector[frame].est_c2w : cur_c2w;
-            torch::Tensor ro, rd, gd, gc, pi, pj;
-            get_samples(0, H, 0, W, pixs_per_image, H, W, fx, fy, cx, cy, c2w, gt_depth, gt_color, ro, rd, gd, gc, &pi, &pj);
-            torch::Tensor keep = inside_mask(bound, ro, rd, gd);                              // :416-427, per frame (same rays kept)
-            v_ro.push_back(ro.index({keep})); v_rd.push_back(rd.index({keep})); v_gd.push_back(gd.index({keep}));
-            v_gc.push_back(gc.index({keep})); v_pi.push_back(pi.index({keep})); v_pj.push_back(pj.index({keep}));
-            v_cam.push_back(cam_id);
-        }
-        torch::Tensor ro = torch::cat(v_ro).contiguous(), rd = torch::cat(v_rd).contiguous();
-        torch::Tensor gd = torch::cat(v_gd).contiguous(), gc = torch::cat(v_gc).contiguous();
-        const int N = (int)ro.size(0);
-        if (N == 0) continue;
-        d_ro.upload(ro); d_rd.upload(rd); d_gd.upload(gd); d_gc.upload(gc);
-        unsigned flags = NSK_GRAD_GRIDS | NSK_GRAD_DECODERS;
-        if (ba_now) { flags |= NSK_GRAD_RAYS; d_gro.ensure((size_t)N * 3); d_grd.ensure((size_t)N * 3); }
-        // the reference renders with the literal "color" whatever the stage (:430, D19); the intended graph renders `stage`
-        check(nsk_map_step(ctx(), nskh::stage_id(stage), N, d_ro.p, d_rd.p, d_gd.p, d_gc.p, -1.f, w_color_loss, stage == "color" ? 1 : 0, flags,
-                           d_loss.p, nullptr, nullptr, nullptr, ba_now ? d_gro.p : nullptr, ba_now ? d_grd.p : nullptr));      // :430-444
-        if (ba_now) {         // pose gradients per frame through the ray generator and quad2rotation
-            torch::Tensor g_ro = d_gro.download({N, 3}), g_rd = d_grd.download({N, 3});
-            int64_t off = 0;
-            for (size_t f = 0; f < v_ro.size(); ++f) {
-                int64_t n = v_ro[f].size(0);
-                if (v_cam[f] >= 0 && n > 0) {
-                    torch::Tensor cam = camera_tensor_list[v_cam[f]].detach();
-                    torch::Tensor i = v_pi[f].to(torch::kFloat32), j = v_pj[f].to(torch::kFloat32);
-                    torch::Tensor dirs = torch::stack({(i - cx) / fx, -(j - cy) / fy, -torch::ones_like(i)}, -1);        // [n,3]
-                    torch::Tensor gR = torch::matmul(g_rd.slice(0, off, off + n).t(), dirs);                              // [3,3]
-                    torch::Tensor gt = g_ro.slice(0, off, off + n).sum(0);                                                // [3]
-                    torch::Tensor q = cam.clone().requires_grad_(true);                                                   // 9x4 Jacobian of quad2rotation on the host
-                    torch::Tensor RT = get_camera_from_tensor(q);
-                    ((RT.index({Slice(), Slice(None, 3)}) * gR).sum() + (RT.index({Slice(), 3}) * gt).sum()).backward();
-                    camera_tensor_list[v_cam[f]].mutable_grad() = q.grad().clone();
-                }
-                off += n;
+        check(nsk_inside_filter(ctx(), N, R.ro.p, R.rd.p, R.gd.p, R.keep.p));                // :416-427: rays that leave the bound before their depth
+        check(nsk_set_ray_mask(ctx(), R.keep.p));                                             // ... are neutralised in place (no count on the host)
+        unsigned flags = NSK_GRAD_GRIDS | NSK_GRAD_DECODERS | (ba_now ? NSK_GRAD_RAYS : 0u);
+        // src/Mapper.cpp:430 renders the literal "color" whatever the stage (D19); the colour term of the loss follows `stage` (:438)
+        const std::string render_stage = (render_stage_literal_color && !coarse_mapper) ? std::string("color") : stage;
+        check(nsk_map_step(ctx(), nskh::stage_id(render_stage), N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, stage == "color" ? 1 : 0, flags,
+                           D.loss.p, nullptr, nullptr, nullptr, ba_now ? R.g_ro.p : nullptr, ba_now ? R.g_rd.p : nullptr));      // :430-444
+        check(nsk_set_ray_mask(ctx(), nullptr));
+        check(nsk_adam_step(ctx(), lr, 0.9f, 0.999f, 1e-8f));                                 // :445-446
+        if (ba_now) {                                                                         // pose gradients through the ray generator and quad2rotation + Adam, per frame
+            ++ba_step;
+            for (int i = 0; i < nf; ++i) {
+                if (!is_ba[i]) continue;
+                const size_t o = (size_t)i * pixs_per_image;
+                check(nsk_pose_step(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, fx, fy, cx, cy, 0, R.g_ro.p + 3 * o, R.g_rd.p + 3 * o, D.cams.p + 8 * i,
+                                    D.cam_m.p + 8 * i, D.cam_v.p + 8 * i, BA_cam_lr, 0.9f, 0.999f, 1e-8f, ba_step, nullptr));
             }
         }
-        check(nsk_adam_step(ctx(), lr, 0.9f, 0.999f, 1e-8f));                                 // :445-446
-        if (cam_opt) { if (ba_now) cam_opt->step(); cam_opt->zero_grad(); }
     }
-    last_loss = d_loss.download({4}).index({0}).item<float>();
+    check(nsk_sync(ctx()));
+    last_iter_us = (now_us() - t0) / num_joint_iters_;
+    D.loss.download(&last_loss, 1);                                                           // the only per-call device-to-host traffic besides the results
     nskh::fetch_grids(c);                                                                     // :448-464 (once instead of per iteration)
     decoders.fetch_from_device(!fix_fine, !fix_color);
-    if (BA) {                                                                                 // :467-489
+    if (any_ba) {                                                                             // :467-489
+        D.cams.download(h_cam.data(), h_cam.size());
         torch::Tensor bottom = torch::tensor({{0.f, 0.f, 0.f, 1.f}});
-        int camera_tensor_id = 0;
-        for (int frame : optimize_frame) {
-            if (frame == oldest_frame) continue;
-            torch::Tensor c2w = torch::cat({get_camera_from_tensor(camera_tensor_list[camera_tensor_id++].detach()), bottom}, 0);
-            if (frame != -1) keyframe_vector[frame].est_c2w = c2w; else cur_c2w = c2w;        // D24: .back()
+        for (int i = 0; i < nf; ++i) {
+            if (!is_ba[i]) continue;
+            torch::Tensor cam = torch::from_blob(h_cam.data() + 8 * i, {7}, torch::kFloat32).clone();
+            torch::Tensor c2w = torch::cat({get_camera_from_tensor(cam), bottom}, 0);
+            const int f = optimize_frame[i];
+            if (f != -1) keyframe_vector[f].est_c2w = c2w; else cur_c2w = c2w;                // D24: .back()
         }
     }
 }

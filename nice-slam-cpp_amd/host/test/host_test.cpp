@@ -1,6 +1,7 @@
 // host_test.cpp -- exercises the C++ host classes (reference surface) end to end on the GPU and dumps inputs / outputs
 // as .npy files for tests/test_gpu_host_cpp.py, which checks them against the CPU oracle.
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -126,8 +127,13 @@ int main(int argc, char** argv)
         torch::Tensor l0 = tracker.optimize_cam_in_batch(cam_t, color_img, depth_img, 100, opt, decoders);
         torch::Tensor l1 = tracker.optimize_cam_in_batch(cam_t, color_img, depth_img, 100, opt, decoders);
         save_npy(out + "trk_cam2.npy", cam_t); save_npy(out + "trk_loss.npy", torch::stack({l0, l1}));
+        tracker.seed(1000);                                                // iteration i of run() draws its pixels with seed 1000 + i
         tracker.run(decoders, color_img, depth_img, c2w, 0);
         save_npy(out + "trk_run_cam.npy", tracker.last_camera_tensor);
+        save_npy(out + "trk_run_losses.npy", torch::tensor(tracker.last_losses));
+        save_npy(out + "trk_color_img.npy", color_img);
+        tracker.run(decoders, color_img, depth_img, c2w, 1);               // a second frame: buffers and images are reused, nothing is reallocated
+        std::printf("Tracker::run device-resident: %.1f us per iteration (%d iterations, %d rays)\n", tracker.last_run_us / 3.0, 3, 100);
 
         // ---- Mapper::run (first frame: iters_first, lr_first_factor) then a second frame with a keyframe in the window
         Mapper mapper(ns, cf, false);
@@ -142,7 +148,24 @@ int main(int argc, char** argv)
         float loss_a = mapper.last_loss;
         mapper.run(decoders, c, est, color_img, depth_img, c2w, 1, 10);
         float loss_b = mapper.last_loss;
+        std::printf("Mapper::optimize_map device-resident: %.1f us per iteration (200 rays over the window)\n", mapper.last_iter_us);
         save_npy(out + "map_loss.npy", torch::tensor({loss_a, loss_b}));
+        // the thin methods of the reference's surface (include/Mapper.h:24-25)
+        {
+            cv::Mat depth_mat(H, W, CV_32FC1);
+            std::memcpy(depth_mat.data, depth_img.data_ptr<float>(), sizeof(float) * H * W);
+            torch::Tensor m;
+            mapper.get_mask_from_c2w(depth_mat, c2w, torch::tensor({(int64_t)6, (int64_t)5, (int64_t)7}), "grid_middle", m);      // val_shape = (Z,Y,X) (:258)
+            save_npy(out + "thin_mask_middle_xyz.npy", m.to(torch::kFloat32));
+            KeyFrame k0; k0.est_c2w = c2w.clone();
+            KeyFrame k1; k1.est_c2w = c2w.clone(); k1.est_c2w[0][0] = -1.f; k1.est_c2w[2][2] = -1.f;      // looks the other way: no overlap
+            std::vector<int> sel;
+            mapper.keyframe_selection_overlap(color_img, depth_img, c2w, std::vector<KeyFrame>{k1, k0}, 3, sel);
+            torch::Tensor st = torch::zeros({(int64_t)sel.size()});
+            for (size_t k = 0; k < sel.size(); ++k) st[k] = (float)sel[k];
+            save_npy(out + "thin_selected.npy", st.numel() ? st : torch::full({1}, -7.f));
+            save_npy(out + "thin_overlap.npy", torch::tensor(mapper.last_overlap));
+        }
         for (auto k : {"grid_middle", "grid_fine", "grid_color"}) save_npy(out + "map_" + k + ".npy", c.at(k));
         save_npy(out + "map_dec_color_delta.npy", (decoders.color_decoder->packed() - color_before).abs().max().reshape({1}));
         save_npy(out + "map_dec_fine_delta.npy", (decoders.fine_decoder->packed() - fine_before).abs().max().reshape({1}));

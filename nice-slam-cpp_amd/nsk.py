@@ -17,7 +17,7 @@ GROUP_DECODERS, GROUP_COARSE, GROUP_MIDDLE, GROUP_FINE, GROUP_COLOR, GROUP_CAMER
 # every symbol include/nsk.h declares
 SYMBOLS = (
     "nsk_last_error", "nsk_version", "nsk_ctx_create", "nsk_ctx_destroy", "nsk_sync", "nsk_stream", "nsk_set_bound",
-    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_set_sort_mode", "nsk_set_tuning", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap", "nsk_sample_pixels", "nsk_gather_pixels", "nsk_rays_from_camera", "nsk_pose_step",
+    "nsk_set_render_opts", "nsk_set_matmul_mode", "nsk_set_sort_mode", "nsk_set_tuning", "nsk_set_ray_mask", "nsk_grid_upload", "nsk_grid_download", "nsk_grid_grad_download", "nsk_set_mask", "nsk_frustum_mask", "nsk_keyframe_overlap", "nsk_sample_pixels", "nsk_gather_pixels", "nsk_rays_from_camera", "nsk_pose_step",
     "nsk_decoder_param_count", "nsk_decoder_upload", "nsk_decoder_download", "nsk_decoder_grad_download",
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
@@ -142,6 +142,11 @@ class Context:
 
     def set_matmul_mode(self, mode):
         _chk(lib().nsk_set_matmul_mode(self.h, int(mode)))
+
+    def set_ray_mask(self, keep):
+        """uint8 cuda tensor [N] (or None): rays with keep == 0 take no part in the loss, its gradients and the batch statistics"""
+        self._ray_mask = keep                     # keep the tensor alive while the context points at it
+        _chk(lib().nsk_set_ray_mask(self.h, _ptr(keep) if keep is not None else None))
 
     def set_sort_mode(self, mode):
         """-1 automatic, 0 ray order, 1 cell-sorted (include/nsk.h)"""

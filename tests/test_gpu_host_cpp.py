@@ -71,6 +71,52 @@ def test_tracker_moves_the_pose_and_reports_a_loss(dump):
     assert np.isfinite(dump["trk_run_cam"]).all() and dump["trk_run_cam"].shape == (7,)
 
 
+def test_tracker_run_matches_oracle_on_the_same_pixel_draws(dump, oracle32, oracle64):
+    """Tracker::run (src/Tracker.cpp:92-113) through the C++ class, every iteration resident on the device: pixel draw (counter-based
+    hash, seed 1000 + i), ground-truth gather, rays from the pose, bound filter, render, loss with the dynamic-outlier median, backward
+    onto the pose, Adam.  The oracle repeats the loop on the same draws; the pose after config `tracking.iters` = 3 iterations at
+    `tracking.lr` = 1e-3 and the three losses must agree."""
+    bound, grids, decs = _scene(dump)
+    H, W, fx, fy, cx, cy = 48, 64, 40.0, 40.0, 32.0, 24.0
+    depth_img, color_img, c2w = dump["map_depth_img"], dump["trk_color_img"], dump["map_c2w"]
+
+    def run(o):
+        cam = np.concatenate([[1.0, 0.0, 0.0, 0.0], c2w[:3, 3]]).astype(o.dt)         # get_tensor_from_camera of an identity rotation
+        m, v = np.zeros(7, o.dt), np.zeros(7, o.dt)
+        losses = []
+        for i in range(3):
+            pi, pj = o.sample_pixels(1000 + i, 100, 4, H - 4, 4, W - 4)
+            gd, gc = o.gather_pixels(pi, pj, depth_img, color_img)
+            ro, rd = o.rays_from_pixels(pi, pj, fx, fy, cx, cy, o.camera_from_tensor(cam))
+            keep = o.inside_filter(bound, ro, rd, gd)
+            op = o.opts(bound)
+            fw = o.render_forward(op, grids, decs, "color", ro[keep], rd[keep], gd[keep])
+            l, gD, gC, gV = o.loss_track(fw["depth"], fw["rgb"], fw["var"], gd[keep], gc[keep], 0.5, True, True, True)
+            bw = o.render_backward(op, grids, decs, "color", ro[keep], rd[keep], gd[keep], -1.0, gC, gD, None, want_grids=False, want_decoders=False)
+            g = o.camera_backward(cam, o.rays_backward(pi[keep], pj[keep], fx, fy, cx, cy, bw["g_rays_o"], bw["g_rays_d"]))
+            o.adam_step(cam, g, m, v, 1e-3, i + 1)
+            losses.append(l)
+        return cam, losses
+    cam32, l32 = run(oracle32)
+    cam64, _ = run(oracle64)
+    got = dump["trk_run_cam"]
+    assert np.abs(cam32[4:] - c2w[:3, 3]).max() > 1e-3                                  # the three steps moved the pose
+    for a, r in zip(dump["trk_run_losses"], l32):
+        assert abs(a - r) < 1e-3 * abs(r), (a, r)
+    e, e64, eo = rel_l2(got, cam32), rel_l2(got, cam64), rel_l2(cam32, cam64)
+    assert e < 1e-4 or e64 < 2 * eo + 1e-4, (e, e64, eo)
+
+
+def test_thin_mapper_methods_of_the_reference_surface(dump, oracle32):
+    """Mapper::get_mask_from_c2w(cv::Mat, ...) and Mapper::keyframe_selection_overlap(...) (include/Mapper.h:24-25) as thin methods"""
+    bound, grids, decs = _scene(dump)
+    fm = oracle32.frustum_mask(bound, grids["middle"].shape[1:], dump["map_depth_img"], (40.0, 40.0, 32.0, 24.0), dump["map_c2w"])     # [Z,Y,X]
+    got = dump["thin_mask_middle_xyz"] > 0.5                                            # [X,Y,Z] like the reference's result
+    assert got.shape == fm.shape[::-1] and np.array_equal(got.transpose(2, 1, 0), fm)
+    assert [int(x) for x in dump["thin_selected"]] == [1]                               # keyframe 1 sees the frame, keyframe 0 looks away (dropped: 0 overlap)
+    assert dump["thin_overlap"][0] == 0 and dump["thin_overlap"][1] > 0.02             # (20-pixel edge of a 64x48 image: a small window)
+
+
 def test_mapper_optimises_grids_and_colour_decoder(dump, oracle32):
     bound, grids, decs = _scene(dump)
     assert np.isfinite(dump["map_loss"]).all()

@@ -55,12 +55,12 @@ STAGE_LR = {"coarse": [0.0, 0.001, 0.0, 0.0, 0.0, 0.0], "middle": [0.0, 0.0, 0.1
 def workloads():
     import scenes
     return {
-        "K3": dict(bound=scenes.K3_BOUND, cam=scenes.CAM_SCANNET, rays=5000,
+        "K3": dict(bound=scenes.K3_BOUND, cam=scenes.CAM_SCANNET, rays=5000, up="z",
                    name="configs[2]: ScanNet scene0000_00-class room (bound [[0,8.6],[0,8.9],[-0.3,3.3]], 640x480 camera; declared in the "
                         "harness, the reference holds no such config), grids of src/main.cpp:34-75 for that bound"),
-        "K2": dict(bound=scenes.REF_BOUND, cam=scenes.CAM_NICE_SLAM, rays=1000,
+        "K2": dict(bound=scenes.REF_BOUND, cam=scenes.CAM_NICE_SLAM, rays=1000, up="y",
                    name="configs[1]: config/nice_slam.yaml grids (bound of src/main.cpp:33, Replica-room0-class), 1200x680 camera"),
-        "K4": dict(bound=scenes.K4_BOUND, cam=scenes.CAM_NICE_SLAM, rays=1250,
+        "K4": dict(bound=scenes.K4_BOUND, cam=scenes.CAM_NICE_SLAM, rays=1250, up="z",
                    name="configs[3] shard: Replica office0-class room, 10000 rays / 8 GPUs = 1250 rays per GPU"),
     }
 
@@ -170,7 +170,7 @@ def cpu_baseline_aten(sc, rays_list, stage, lr, w_color, seconds):
             "ms_per_step": 1e3 * dt / steps}
 
 
-def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, keep=False):
+def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, frustum=True):
     """time `steps` mapping iterations of workload `wl` at `N` rays per GPU; returns dict(dt, prof, loss, scene, pool)"""
     import nice_slam_cpp_amd as pkg
     import nice_slam_cpp_amd.dist as nd
@@ -178,10 +178,18 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
     dev = torch.device("cuda", local)
     cam = wl["cam"]
     sc = scenes.make_scene(42, scenes.grid_shapes_for(wl["bound"]), bound=wl["bound"])     # grid shapes + init of src/main.cpp:33-78
-    pool = [scenes.make_rays(1234 + 17 * i + 1000 * rank, N, sc["bound"], n_frames=5, **cam) for i in range(8)]
+    # one optimize_map call: a fixed window of 5 frames (4 keyframes + the current frame, mapping_window_size 5), fresh random pixels of
+    # those frames every iteration (src/Mapper.cpp:376-414); every rank draws its own pixels of the same frames
+    pool = [scenes.make_rays(1234 + 17 * i + 1000 * rank, N, sc["bound"], n_frames=5, cam_seed=4242, up=wl["up"], **cam) for i in range(8)]
     ctx = pkg.Context(local)
     ctx.set_render_opts()                                        # 32 + 16 samples (src/Renderer.cpp:9-10)
     ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
+    mask_frac = None
+    if frustum:                                                  # mapping.frustum_feature_selection: True (nice_slam.yaml:62): the optimiser
+        c2w_cur = pool[0]["c2w"][-1]                             # parameters are the voxels in the current frame's frustum (Mapper.cpp:254-290)
+        depth_img = torch.tensor(scenes.frame_depth_image(sc["bound"], c2w_cur, **cam), device=dev)
+        intr = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        mask_frac = {k: float(ctx.frustum_mask(k, depth_img, intr, c2w_cur).mean()) for k in ("coarse", "middle", "fine", "color")}
     train_color = stage == "color"
     ctx.decoder_set_trainable("color", train_color)              # fix_fine: True, fix_color: False (nice_slam.yaml:51-52)
     lr = STAGE_LR[stage]
@@ -196,13 +204,16 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
     flags = pkg.nsk.GRAD_GRIDS | (pkg.nsk.GRAD_DECODERS if train_color else 0)
 
     with torch.cuda.stream(ctx.tstream):
-        slab = ctx.grad_slab() if world > 1 else None            # wraps context memory once; nsk_grad_slab is still called per step below
+        xn = [0]
 
         def step(i):
             ro, rd, gd, gc, gmax = batches[i % len(batches)]
             ctx.map_step(stage, ro, rd, gd, gc, gmax, w_color, stage == "color", flags=flags, loss=loss)
-            if world > 1:                                        # the one exchange of the path; grad_slab() completes the
-                nd.allreduce_grads(ctx.grad_slab())              # step's pending gradient reductions before it is read
+            if world > 1:                                        # the one exchange of the path: the marked voxels of the touched levels,
+                buf = ctx.grad_pack()                            # the colour decoder's gradient and the loss (nsk_grad_pack)
+                xn[0] = buf.numel()
+                nd.allreduce_grads(buf)
+                ctx.grad_unpack()
             ctx.adam_step(lr)
 
         eager_step = step
@@ -238,7 +249,12 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
             eager_step(warmup + i)
         prof = ctx.profile_end()
         final_loss = float(loss)
-    out = dict(dt=dt, prof=prof, loss=final_loss, sc=sc, pool=pool, lr=lr, w_color=w_color, slab_floats=int(ctx.grad_slab().numel()))
+        if world == 1:                                           # what an exchange would carry (reported also for N = 1)
+            ctx.map_step(stage, *batches[0][:4], batches[0][4], w_color, stage == "color", flags=flags, loss=loss)
+            xn[0] = ctx.grad_pack().numel()
+            ctx.zero_grads()
+    out = dict(dt=dt, prof=prof, loss=final_loss, sc=sc, pool=pool, lr=lr, w_color=w_color, slab_floats=int(ctx.grad_slab().numel()),
+               exchange_floats=int(xn[0]), mask_frac=mask_frac)
     ctx.close()
     return out
 
@@ -279,6 +295,7 @@ def main():
     ap.add_argument("--stage", default="color")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the K2 / fine-stage / K4-shard lines under 'extras'")
+    ap.add_argument("--no-frustum-mask", action="store_true", help="optimise every voxel (mapping.frustum_feature_selection: False)")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step as a captured hipGraph (single GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of each CPU baseline's timed sample")
     args = ap.parse_args()
@@ -304,7 +321,7 @@ def main():
     W = workloads()
     wl = W[args.workload]
     N = args.rays or wl["rays"]
-    res = run_workload(wl, args.stage, N, args.steps, args.warmup, local, rank, world, dist, graph=args.graph)
+    res = run_workload(wl, args.stage, N, args.steps, args.warmup, local, rank, world, dist, graph=args.graph, frustum=not args.no_frustum_mask)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -331,7 +348,9 @@ def main():
                    "grid_shapes": {k: list(v.shape) for k, v in res["sc"]["grids"].items()},
                    "matmul": "fp32 operands as bf16 pieces on the matrix cores with fp32 accumulation (3 pieces = fp32-accurate: forward, frozen-decoder "
                              "backward chains), fp32 MFMA for the trainable decoder's chain, its weight-gradient panels and the grid-gradient scatter",
-                   "parallelism": "rays sharded x%d, 1 all-reduce/step of %d floats" % (world, res["slab_floats"])},
+                   "frustum_feature_selection": res["mask_frac"] is not None, "marked_voxel_fraction": res["mask_frac"],
+                   "parallelism": "rays sharded x%d, 1 all-reduce/step of %d floats (%.2f MB: marked voxels of the trained levels + colour decoder + loss; "
+                                  "the dense gradient slab is %d floats)" % (world, res["exchange_floats"], 4e-6 * res["exchange_floats"], res["slab_floats"])},
         "roofline": head["roofline"], "step_rooflines": head["step_rooflines"], "kernels": head["kernels"], "final_loss": head["final_loss"],
     }
     if world == 1 and not args.no_extras:
@@ -340,7 +359,7 @@ def main():
                                          ("K4_shard_color", "K4", "color", W["K4"]["rays"], 100)):
             if wname == args.workload and stage == args.stage and n == N:
                 continue
-            r = run_workload(W[wname], stage, n, k, 10, local, rank, world, None)
+            r = run_workload(W[wname], stage, n, k, 10, local, rank, world, None, frustum=not args.no_frustum_mask)
             s = summarize(r, stage, n, k, 1)
             extras[name] = {"workload": W[wname]["name"], "stage": stage, "rays": n, "steps": k, "value": s["value"], "unit": "rays/s",
                             "ms_per_step": s["ms_per_step"], "roofline_frac": s["roofline"]["frac"], "roofline_kernel": s["roofline"]["kernel"],

@@ -248,7 +248,15 @@ int nsk_zero_grads(nsk_ctx* ctx);
  * nsk_decoder_grad_download complete that sum first, so call nsk_grad_slab after nsk_map_step, every step, before reading
  * or exchanging the slab yourself. */
 int nsk_grad_slab(nsk_ctx* ctx, float** d_ptr, size_t* n_floats);
-/* ncclAllReduce(sum, fp32) of the slab on the context's stream; comm is an ncclComm_t (RCCL). */
+/* The exchange in compact form.  Every rank holds the same optimiser masks (nsk_set_mask / nsk_frustum_mask), and Adam discards the
+ * gradient of an unmarked voxel, so only marked voxels need to travel: nsk_grad_pack gathers, into one contiguous buffer, the marked
+ * voxels of the grid levels that received gradients since the last optimiser step (whole levels where no mask is installed), the
+ * gradients of the trainable decoders and the 4 loss floats; after the caller's all-reduce (sum) over that buffer nsk_grad_unpack
+ * writes the sums back into the slab for nsk_adam_step.  Levels the stage did not touch are not sent at all.  The marked-voxel lists
+ * are rebuilt only when a mask changes (ascending voxel order, identical on every rank). */
+int nsk_grad_pack(nsk_ctx* ctx, float** d_ptr, size_t* n_floats);
+int nsk_grad_unpack(nsk_ctx* ctx);
+/* nsk_grad_pack + ncclAllReduce(sum, fp32) on the context's stream + nsk_grad_unpack; comm is an ncclComm_t (RCCL). */
 int nsk_allreduce_grads(nsk_ctx* ctx, void* nccl_comm);
 
 /* ---- introspection for benchmarks ------------------------------------------------------------------------ */

@@ -126,6 +126,46 @@ __global__ void k_adam_multi(AdamArgs A)
     }
 }
 
+// Mask-compacted gradient exchange (multi-GPU): every rank holds the same optimiser mask, so only the marked voxels' gradients need to
+// travel.  k_mask_index lists them in ascending order (one workgroup, deterministic: every rank must build the same list),
+// k_grad_gather / k_grad_scatter move their 32-float lines between the dense gradient slab and the packed exchange buffer.
+__global__ __launch_bounds__(1024) void k_mask_index(int nvox, const uint8_t* __restrict__ mask, int* __restrict__ idx, int* __restrict__ count)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int v0 = 0; v0 < nvox; v0 += 1024) {
+        const int v = v0 + threadIdx.x;
+        const bool on = v < nvox && mask[v];
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(on);
+        if (lane == 0) wsum[wave] = __builtin_popcountll(b);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (on) idx[off + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+__global__ void k_grad_gather(int n, const int* __restrict__ idx, const float* __restrict__ g, float* __restrict__ packed)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;          // one float4 per thread, 8 per voxel
+    if (t >= n * 8) return;
+    const int v = idx ? idx[t >> 3] : (t >> 3);
+    reinterpret_cast<f4*>(packed)[t] = reinterpret_cast<const f4*>(g)[(size_t)v * 8 + (t & 7)];
+}
+__global__ void k_grad_scatter(int n, const int* __restrict__ idx, const float* __restrict__ packed, float* __restrict__ g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 8) return;
+    const int v = idx ? idx[t >> 3] : (t >> 3);
+    reinterpret_cast<f4*>(g)[(size_t)v * 8 + (t & 7)] = reinterpret_cast<const f4*>(packed)[t];
+}
+
 struct PackSeg { float* img; const int* idx; const float* P; int n; int blk_end; };
 struct PackArgs { PackSeg s[8]; int n; };
 __global__ void k_pack_multi(PackArgs A)
@@ -524,6 +564,7 @@ struct GridState {
     float* v = nullptr; float* m = nullptr; float* s = nullptr;
     uint8_t* mask = nullptr;
     size_t g_off = 0;            // offset in the gradient slab
+    int* midx = nullptr; int nmask = 0; bool midx_dirty = true;      // ascending list of the marked voxels (packed gradient exchange)
 };
 struct DecState {
     int n = 0;
@@ -563,6 +604,9 @@ struct nsk_ctx {
     GridState grid[4];
     DecState dec[4];
     float* slab = nullptr; size_t slab_n = 0;
+    float* xbuf = nullptr; size_t xbuf_cap = 0; size_t xbuf_n = 0;     // packed exchange buffer (nsk_grad_pack) and its current length
+    bool x_identity = false;                                              // the last pack handed out the slab itself (no masks)
+    bool xlevels[4] = {false, false, false, false}; bool xdecs[4] = {false, false, false, false};      // what the last pack holds
     Workspace ws;
     float* scal = nullptr;       // [0] gt max, [1] median threshold, [2] loss, [4] frustum max depth (bits)
     void* fr_tmp = nullptr; size_t fr_cap = 0;      // nsk_frustum_mask scratch
@@ -695,12 +739,12 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (int i = 0; i < 4; ++i) {
-        hipFree(c->grid[i].v); hipFree(c->grid[i].m); hipFree(c->grid[i].s); hipFree(c->grid[i].mask);
+        hipFree(c->grid[i].v); hipFree(c->grid[i].m); hipFree(c->grid[i].s); hipFree(c->grid[i].mask); hipFree(c->grid[i].midx);
         hipFree(c->dec[i].p); hipFree(c->dec[i].m); hipFree(c->dec[i].s); hipFree(c->dec[i].fimg); hipFree(c->dec[i].bimg);
         hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv); hipFree(c->dec[i].inv16); hipFree(c->dec[i].bimg16); hipFree(c->dec[i].bidx16);
         hipFree(c->dec[i].fimg16); hipFree(c->dec[i].fidx16);
     }
-    hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal); hipFree(c->fr_tmp);
+    hipFree(c->xbuf); hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal); hipFree(c->fr_tmp);
     free_ws(c->ws);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -794,7 +838,7 @@ extern "C" int nsk_grid_upload(nsk_ctx* c, int level, const float* h, int C, int
         HIPCHK(hipMalloc(&G.v, n * 4)); HIPCHK(hipMalloc(&G.m, n * 4)); HIPCHK(hipMalloc(&G.s, n * 4));
     }
     if (G.Z != Z || G.Y != Y || G.X != X) { if (G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); invalidate_graphs(c); hipFree(G.mask); G.mask = nullptr; } }
-    G.C = C; G.Z = Z; G.Y = Y; G.X = X; G.n = n;
+    G.C = C; G.Z = Z; G.Y = Y; G.X = X; G.n = n; G.midx_dirty = true;
     std::vector<float> t(n);
     for (int ch = 0; ch < 32; ++ch)
         for (size_t v = 0; v < nvox; ++v) t[v * 32 + ch] = h[(size_t)ch * nvox + v];
@@ -836,6 +880,7 @@ extern "C" int nsk_set_mask(nsk_ctx* c, int level, const uint8_t* h_mask)
     if (!G.n) return fail("nsk_set_mask: grid level %d not uploaded", level);
     HIPCHK(hipStreamSynchronize(c->stream));
     size_t nvox = G.n / 32;
+    G.midx_dirty = true;
     if (!h_mask) { if (G.mask) { invalidate_graphs(c); hipFree(G.mask); G.mask = nullptr; } return 0; }
     if (!G.mask) { invalidate_graphs(c); HIPCHK(hipMalloc(&G.mask, nvox)); }
     HIPCHK(hipMemcpy(G.mask, h_mask, nvox, hipMemcpyHostToDevice));
@@ -1666,6 +1711,7 @@ extern "C" int nsk_frustum_mask(nsk_ctx* c, int level, const float* d_depth, int
     if (!G.n) return fail("nsk_frustum_mask: grid level %d not uploaded", level);
     HIPCHK(hipSetDevice(c->device));
     const size_t nvox = G.n / 32;
+    G.midx_dirty = true;
     if (!G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); invalidate_graphs(c); HIPCHK(hipMalloc(&G.mask, nvox)); }
     if (level == NSK_COARSE) {                                   // src/Mapper.cpp:54-59
         HIPCHK(hipMemsetAsync(G.mask, 1, nvox, c->stream));
@@ -2002,10 +2048,103 @@ extern "C" int nsk_grad_slab(nsk_ctx* c, float** p, size_t* n)
     return 0;
 }
 
+// Which parts of the slab a step's exchange must carry: the grid levels and trainable decoders that received gradients since the
+// last optimiser step (the same on every rank: it follows from the stage and the flags) and the loss scalars.
+static int pack_layout(nsk_ctx* c, size_t* total)
+{
+    size_t n = 0;
+    for (int l = 0; l < 4; ++l) {
+        GridState& G = c->grid[l];
+        c->xlevels[l] = G.n && c->touched[NSK_GROUP_COARSE + l];
+        if (!c->xlevels[l]) continue;
+        if (G.mask && G.midx_dirty) {
+            const int nvox = (int)(G.n / 32);
+            if (!G.midx) HIPCHK(hipMalloc(&G.midx, (size_t)nvox * 4));
+            int* d_count = reinterpret_cast<int*>(c->scal + 8);
+            k_mask_index<<<1, 1024, 0, c->stream>>>(nvox, G.mask, G.midx, d_count);
+            HIPCHK(hipMemcpyAsync(&G.nmask, d_count, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));                 // once per mask, not per step
+            G.midx_dirty = false;
+        }
+        n += (size_t)(G.mask ? G.nmask : (int)(G.n / 32)) * 32;
+    }
+    for (int w = 0; w < 4; ++w) {
+        c->xdecs[w] = c->dec[w].loaded && c->dec[w].trainable && c->touched[NSK_GROUP_DECODERS];
+        if (c->xdecs[w]) n += (size_t)((c->dec[w].n + 3) & ~3);
+    }
+    n += 4;
+    *total = n;
+    return 0;
+}
+
+static int pack_move(nsk_ctx* c, bool gather)
+{
+    size_t o = 0;
+    for (int l = 0; l < 4; ++l) {
+        if (!c->xlevels[l]) continue;
+        GridState& G = c->grid[l];
+        const int nv = G.mask ? G.nmask : (int)(G.n / 32);
+        if (nv > 0) {
+            const int blocks = (nv * 8 + 255) / 256;
+            if (gather) k_grad_gather<<<blocks, 256, 0, c->stream>>>(nv, G.mask ? G.midx : nullptr, c->slab + G.g_off, c->xbuf + o);
+            else k_grad_scatter<<<blocks, 256, 0, c->stream>>>(nv, G.mask ? G.midx : nullptr, c->xbuf + o, c->slab + G.g_off);
+        }
+        o += (size_t)nv * 32;
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (!c->xdecs[w]) continue;
+        const size_t n4 = (size_t)((c->dec[w].n + 3) & ~3);
+        if (gather) HIPCHK(hipMemcpyAsync(c->xbuf + o, c->slab + c->dec[w].g_off, n4 * 4, hipMemcpyDeviceToDevice, c->stream));
+        else HIPCHK(hipMemcpyAsync(c->slab + c->dec[w].g_off, c->xbuf + o, n4 * 4, hipMemcpyDeviceToDevice, c->stream));
+        o += n4;
+    }
+    if (gather) HIPCHK(hipMemcpyAsync(c->xbuf + o, c->slab + c->slab_n - 4, 16, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(hipMemcpyAsync(c->slab + c->slab_n - 4, c->xbuf + o, 16, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nsk_grad_pack(nsk_ctx* c, float** p, size_t* n)
+{
+    if (!c || !p || !n) return fail("nsk_grad_pack: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(flush_pending(c));
+    size_t total = 0;
+    CHK(pack_layout(c, &total));
+    bool any_mask = false;
+    for (int l = 0; l < 4; ++l) any_mask = any_mask || (c->xlevels[l] && c->grid[l].mask);
+    if (!any_mask) {                                   // nothing to compact: exchange the slab in place (no copies); unpack is then a no-op
+        c->xbuf_n = 0; c->x_identity = true;
+        *p = c->slab; *n = c->slab_n;
+        return 0;
+    }
+    c->x_identity = false;
+    if (total > c->xbuf_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        invalidate_graphs(c);
+        hipFree(c->xbuf);
+        HIPCHK(hipMalloc(&c->xbuf, total * 4));
+        c->xbuf_cap = total;
+    }
+    c->xbuf_n = total;
+    { ProfScope ps(c, "grad_pack"); CHK(pack_move(c, true)); }
+    *p = c->xbuf; *n = total;
+    return 0;
+}
+
+extern "C" int nsk_grad_unpack(nsk_ctx* c)
+{
+    if (!c) return fail("null ctx");
+    if (c->x_identity) return 0;
+    if (!c->xbuf || !c->xbuf_n) return fail("nsk_grad_unpack: nothing was packed (call nsk_grad_pack after nsk_map_step)");
+    HIPCHK(hipSetDevice(c->device));
+    ProfScope ps(c, "grad_unpack");
+    return pack_move(c, false);
+}
+
 extern "C" int nsk_allreduce_grads(nsk_ctx* c, void* comm)
 {
     if (!c || !comm) return fail("nsk_allreduce_grads: null argument");
-    CHK(flush_pending(c));
     typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
     static allreduce_t fn = nullptr;
     if (!fn) {
@@ -2015,10 +2154,12 @@ extern "C" int nsk_allreduce_grads(nsk_ctx* c, void* comm)
         fn = (allreduce_t)dlsym(h, "ncclAllReduce");
         if (!fn) return fail("nsk_allreduce_grads: ncclAllReduce not found");
     }
+    float* buf = nullptr; size_t n = 0;
+    CHK(nsk_grad_pack(c, &buf, &n));
     const int ncclFloat32 = 7, ncclSum = 0;
-    int r = fn(c->slab, c->slab, c->slab_n, ncclFloat32, ncclSum, comm, c->stream);
+    int r = fn(buf, buf, n, ncclFloat32, ncclSum, comm, c->stream);
     if (r != 0) return fail("ncclAllReduce failed with %d", r);
-    return 0;
+    return nsk_grad_unpack(c);
 }
 
 extern "C" int nsk_profile_begin(nsk_ctx* c)

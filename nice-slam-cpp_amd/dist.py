@@ -51,7 +51,12 @@ class ShardedMapper:
             gt_depth_max = global_depth_max(gt_depth, self.group)
         self.backend.map_step(stage, rays_o, rays_d, gt_depth, gt_color, gt_depth_max, w_color, use_color, flags=flags, loss=loss)
         if _world(self.group) > 1:
-            # grad_slab() also completes the step's pending gradient reductions: call it every step, before the exchange
-            allreduce_grads(self.backend.grad_slab(), self.group)
+            if hasattr(self.backend, "grad_pack"):
+                # compact exchange: only the voxels the (rank-identical) optimiser masks mark, only the levels the stage touched
+                allreduce_grads(self.backend.grad_pack(), self.group)
+                self.backend.grad_unpack()
+            else:
+                # grad_slab() also completes the step's pending gradient reductions: call it every step, before the exchange
+                allreduce_grads(self.backend.grad_slab(), self.group)
         self.backend.adam_step(lr)
         return gt_depth_max

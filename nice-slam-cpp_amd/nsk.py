@@ -22,7 +22,7 @@ SYMBOLS = (
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
     "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
-    "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_grad_slab", "nsk_allreduce_grads", "nsk_last_call_stats",
+    "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_grad_slab", "nsk_grad_pack", "nsk_grad_unpack", "nsk_allreduce_grads", "nsk_last_call_stats",
     "nsk_profile_begin", "nsk_profile_end",
 )
 
@@ -449,6 +449,27 @@ class Context:
             self._slab_t = torch.as_tensor(_CudaArray(p.value, n.value), device="cuda:%d" % self.device)
             self._slab_key = key
         return self._slab_t
+
+    @_ordered
+    def grad_pack(self):
+        """the step's exchange buffer (marked voxels of the touched levels + trainable decoders + loss) as a torch tensor aliasing
+        context memory: all-reduce it, then call grad_unpack()"""
+        import torch
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(lib().nsk_grad_pack(self.h, C.byref(p), C.byref(n)))
+        key = (p.value, n.value)
+        if getattr(self, "_pack_key", None) != key:
+            self._pack_t = torch.as_tensor(_CudaArray(p.value, n.value), device="cuda:%d" % self.device)
+            self._pack_key = key
+        return self._pack_t
+
+    @_ordered
+    def grad_unpack(self):
+        _chk(lib().nsk_grad_unpack(self.h))
+
+    def allreduce_grads_rccl(self, comm):
+        """nsk_allreduce_grads with a raw ncclComm_t (ctypes pointer)"""
+        _chk(lib().nsk_allreduce_grads(self.h, comm))
 
     def profile_begin(self):
         _chk(lib().nsk_profile_begin(self.h))

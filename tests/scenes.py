@@ -16,6 +16,7 @@ K5_BOUND = np.array([[-3.5, 3.0], [-3.0, 3.0], [-3.0, 3.0]], dtype=np.float32)
 CAM_NICE_SLAM = dict(H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5)          # config/nice_slam.yaml:96-102 (K2, K4)
 CAM_SCANNET = dict(H=480, W=640, fx=577.590698, fy=578.729797, cx=318.905426, cy=242.683609)   # K3
 CAM_TUM = dict(H=480, W=640, fx=517.3, fy=516.5, cx=318.6, cy=255.3)                 # K5
+UP = {"K2": "y", "K3": "z", "K4": "z", "K5": "z"}                                     # which world axis is the height in each scene
 GRID_LEN = {"coarse": 2.0, "middle": 0.32, "fine": 0.16, "color": 0.16}              # config/nice_slam.yaml:7-11
 E_DIM, H_DIM = 93, 32
 LEVELS = ("coarse", "middle", "fine", "color")
@@ -95,25 +96,41 @@ def look_rotation(yaw, pitch, roll):
     return Ry @ Rx @ Rz
 
 
-def make_camera(rng, bound):
-    """a pose well inside the room looking roughly along -z (OpenGL camera, utils.h:47)"""
+def make_camera(rng, bound, up="y"):
+    """a pose well inside the room looking roughly horizontally (OpenGL camera, utils.h:47: it looks along its own -z).  up = "y": the
+    world's y axis is the height (the reference's hard-coded bound, src/main.cpp:33); up = "z": z is the height (ScanNet / Replica /
+    TUM conventions: K3-K5), so the camera frame is first turned to look along world +y with its +y along world +z"""
     ctr = bound.mean(axis=1)
     ext = bound[:, 1] - bound[:, 0]
     t = ctr + (rng.uniform(-0.15, 0.15, 3) * ext)
     R = look_rotation(rng.uniform(-0.6, 0.6), rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2))
+    if up == "z":
+        R = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]]) @ R
     c2w = np.eye(4, dtype=np.float32)
     c2w[:3, :3] = R
     c2w[:3, 3] = t
     return c2w
 
 
+def frame_depth_image(bound, c2w, H, W, fx, fy, cx, cy, shrink=0.3):
+    """z-depth image [H,W] of the analytic room (bound shrunk by `shrink`) seen from c2w: what a depth camera of make_rays' scene records"""
+    room = np.asarray(bound, np.float64).copy()
+    room[:, 0] += shrink
+    room[:, 1] -= shrink
+    jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    dirs = np.stack([(ii - cx) / fx, -(jj - cy) / fy, -np.ones_like(ii, dtype=np.float64)], -1).reshape(-1, 3) @ c2w[:3, :3].T.astype(np.float64)
+    o = np.broadcast_to(c2w[:3, 3].astype(np.float64), dirs.shape)
+    return _ray_box_far(room, o, dirs).reshape(H, W).astype(np.float32)
+
+
 def make_rays(seed, n, bound, H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5, n_frames=1, zero_frac=0.05,
-              shrink=0.3, edge=0):
+              shrink=0.3, edge=0, cam_seed=None, up="y"):
     """rays of n seeded pixels split over n_frames seeded cameras (Mapper.cpp:223: pixels/|window| each);
     gt depth = z-depth of the ray/room intersection (room = bound shrunk by `shrink`), zero_frac of them
     set to 0 (Renderer.cpp:94-98 branch); gt colour = smooth function of the hit point.  Intrinsics default
     to config/nice_slam.yaml:97-102."""
     rng = np.random.default_rng(seed)
+    crng = rng if cam_seed is None else np.random.default_rng(cam_seed)      # cam_seed: the same window of cameras for every pixel draw
     bound = np.asarray(bound, np.float32)
     room = bound.astype(np.float64).copy()
     room[:, 0] += shrink
@@ -121,7 +138,7 @@ def make_rays(seed, n, bound, H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=33
     per = n // n_frames
     ro, rd, pi, pj, fr, cams = [], [], [], [], [], []
     for f in range(n_frames):
-        c2w = make_camera(rng, bound)
+        c2w = make_camera(crng, bound, up)
         cams.append(c2w)
         i = rng.integers(edge, W - edge, per)
         j = rng.integers(edge, H - edge, per)

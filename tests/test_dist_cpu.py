@@ -32,6 +32,39 @@ class OracleBackend:
     def grad_slab(self):
         return self.slab
 
+    # the compact exchange of nsk_grad_pack / nsk_grad_unpack: marked voxels only (self.masks: level -> bool [Z,Y,X] or None)
+    masks = None
+
+    def _sel(self, i, k):
+        if self.masks is None or self.masks.get(k) is None:
+            return None
+        return np.flatnonzero(np.broadcast_to(self.masks[k][None], self.grids[k].shape).ravel())
+
+    def grad_pack(self):
+        s = self.slab.numpy()
+        parts = []
+        for i, k in enumerate(self.levels):
+            seg = s[self.off[i]:self.off[i + 1]]
+            sel = self._sel(i, k)
+            parts.append(seg if sel is None else seg[sel])
+        parts.append(s[self.off[3]:])
+        self._packed = torch.tensor(np.concatenate(parts))
+        return self._packed
+
+    def grad_unpack(self):
+        s = self.slab.numpy()
+        p = self._packed.numpy()
+        o = 0
+        for i, k in enumerate(self.levels):
+            sel = self._sel(i, k)
+            n = (self.off[i + 1] - self.off[i]) if sel is None else sel.size
+            if sel is None:
+                s[self.off[i]:self.off[i + 1]] = p[o:o + n]
+            else:
+                s[self.off[i]:self.off[i + 1]][sel] = p[o:o + n]
+            o += n
+        s[self.off[3]:] = p[o:]
+
     def map_step(self, stage, ro, rd, gd, gc, gmax, w_color, use_color, flags=3, loss=None):
         o, op = self.o, self.o.opts(self.bound)
         fw = o.render_forward(op, self.grids, self.decs, stage, ro, rd, gd, gt_depth_max=gmax)
@@ -48,7 +81,8 @@ class OracleBackend:
         s = self.slab.numpy()
         for i, k in enumerate(self.levels):
             g = s[self.off[i]:self.off[i + 1]].reshape(self.grids[k].shape)
-            self.o.adam_step(self.grids[k], g, self.mom[k][0], self.mom[k][1], lr[2 + i], self.t)
+            vm = None if (self.masks is None or self.masks.get(k) is None) else np.broadcast_to(self.masks[k][None], self.grids[k].shape)
+            self.o.adam_step(self.grids[k], g, self.mom[k][0], self.mom[k][1], lr[2 + i], self.t, mask=vm)
         self.o.adam_step(self.decs["color"], s[self.off[3]:self.off[4]].copy(), self.dm, self.dv, lr[0], self.t)
         self.loss = float(s[self.off[4]])
         s[:] = 0
@@ -65,6 +99,12 @@ def _scene_and_rays():
 LR = [0.005, 0.0, 0.005, 0.005, 0.005, 0.0]
 
 
+def _masks(sc):
+    """rank-identical optimiser masks (the frustum mask of the current frame in the real Mapper); one level unmasked"""
+    rng = np.random.default_rng(3)
+    return {"middle": rng.random(sc["grids"]["middle"].shape[1:]) < 0.6, "fine": None, "color": rng.random(sc["grids"]["color"].shape[1:]) < 0.6}
+
+
 def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -74,6 +114,7 @@ def _worker(rank, world, port, out_path):
     sc, rays = _scene_and_rays()
     lo, hi = nd.shard_range(rays["rays_o"].shape[0], rank, world)
     be = OracleBackend(sc)
+    be.masks = _masks(sc)
     mapper = nd.ShardedMapper(be)
     sl = slice(lo, hi)
     gmaxes = []
@@ -102,9 +143,12 @@ def test_two_rank_sharded_mapping_equals_single_process(tmp_path):
     assert float(r0["loss"]) == float(r1["loss"])
     # and equal the single-process full-batch result (fp64 oracle: only the summation order differs)
     be = OracleBackend(sc)
+    be.masks = _masks(sc)
     m = nd.ShardedMapper(be)
     for _ in range(2):
         m.step("color", rays["rays_o"], rays["rays_d"], rays["gt_depth"], rays["gt_color"], LR, gt_depth_max=float(rays["gt_depth"].max()))
     for k, ref in (("fine", be.grids["fine"]), ("color", be.grids["color"]), ("dec", be.decs["color"])):
         assert np.abs(r0[k] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
     assert abs(float(r0["loss"]) - be.loss) < 1e-9 * abs(be.loss)
+    mk = _masks(sc)
+    assert np.array_equal(r0["color"][:, ~mk["color"]], sc["grids"]["color"][:, ~mk["color"]])      # unmarked voxels: never sent, never moved

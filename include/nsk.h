@@ -73,8 +73,13 @@ int nsk_set_matmul_mode(nsk_ctx* ctx, int mode);
  * 0 = ray order always, 1 = cell-sorted always.  Cell-sorted: k_sample also bins every sample by the grid cell it falls in and two small
  * launches build the permutation; tiles of 16 samples then share cells and the backward issues one atomic flush per cell run. */
 int nsk_set_sort_mode(nsk_ctx* ctx, int mode);
-/* performance experiments only (never needed for correct results): key "frozen_cost" = relative cost of a frozen decoder's tile in the
- * backward's workgroup split (0 = built-in value). */
+/* Debug and experiment switches (never needed for correct results):
+ *   "deterministic" 1: bit-reproducible gradients, to tell a real defect from the order sensitivity of floating-point atomics: ray order
+ *                      (no cell sort), one backward launch per decoder in a fixed order, ONE workgroup each whose waves add their tiles'
+ *                      contributions strictly one after the other (orders of magnitude slower; the trainable decoder's pose gradients are
+ *                      not covered);
+ *   "roctx" 1:         roctxRangePush/Pop around every launch group (names as in nsk_profile_end) for rocprofv3 --marker-trace;
+ *   "frozen_cost" n:   relative cost of a frozen decoder's tile in the backward's workgroup split (0 = built-in value). */
 int nsk_set_tuning(nsk_ctx* ctx, const char* key, int value);
 
 /* Scene bound [[x0,x1],[y0,y1],[z0,z1]]; the reference hard-codes it in five places

@@ -623,6 +623,8 @@ struct nsk_ctx {
     struct GraphRec { bool stale = false; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t adam_node = nullptr; bool has_adam = false; CapAdam adam; std::vector<CapVec> vecs; };
     std::vector<GraphRec> graphs;
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
+    bool deterministic = false;             // debug: bit-reproducible gradients (see nsk_set_tuning in include/nsk.h)
+    bool roctx = false;                     // roctx ranges around every profiled launch group (libroctx64, loaded on demand)
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
@@ -636,16 +638,35 @@ struct nsk_ctx {
     std::vector<ProfRec> prof_recs;
 };
 
+// roctx ranges (rocprofv3 --marker-trace shows them around the kernels of each launch group); libroctx64 is loaded on first use
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+static roctx_push_t g_roctx_push = nullptr;
+static roctx_pop_t g_roctx_pop = nullptr;
+static bool roctx_ready()
+{
+    static int state = 0;       // 0 untried, 1 ok, -1 unavailable
+    if (state == 0) {
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (h) { g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA"); g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop"); }
+        state = (g_roctx_push && g_roctx_pop) ? 1 : -1;
+    }
+    return state == 1;
+}
+
 struct ProfScope {      // records start/stop events around the launches issued while it is alive
-    nsk_ctx* c; hipEvent_t a = nullptr, b = nullptr; const char* name;
+    nsk_ctx* c; hipEvent_t a = nullptr, b = nullptr; const char* name; bool ranged = false;
     ProfScope(nsk_ctx* c_, const char* n) : c(c_), name(n)
     {
+        if (c->roctx && roctx_ready()) { g_roctx_push(n); ranged = true; }
         if (!c->prof) return;
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, c->stream);
     }
     ~ProfScope()
     {
+        if (ranged) g_roctx_pop();
         if (!c->prof || !a) return;
         hipEventRecord(b, c->stream);
         c->prof_recs.push_back({name, a, b});
@@ -766,6 +787,8 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
 {
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
+    if (!strcmp(key, "deterministic")) { c->deterministic = value != 0; return 0; }
+    if (!strcmp(key, "roctx")) { c->roctx = value != 0; return 0; }
     return fail("nsk_set_tuning: unknown key '%s'", key);
 }
 
@@ -1244,6 +1267,7 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     int ntasks = (M + 15) / 16;
     size_t lds = bwd_lds_bytes(w, train);
     int grid = std::max(1, std::min((ntasks + 7) / 8, c->num_cu));
+    if (c->deterministic) { grid = 1; A.flags |= 0x8000u; }      // one workgroup, its waves scatter one after the other
     static const char* names[8] = {"decode_bwd_coarse", "decode_bwd_middle", "decode_bwd_fine", "decode_bwd_color",
                                    "decode_bwd_coarse_train", "decode_bwd_middle_train", "decode_bwd_fine_train", "decode_bwd_color_train"};
     {
@@ -1364,6 +1388,7 @@ static void account(nsk_ctx* c, int stage, int M, int N, bool bwd, unsigned flag
 // samples sharing a ray: the Tracker and bundle adjustment keep the ray order)
 static bool sort_pays(nsk_ctx* c, int M, unsigned flags)
 {
+    if (c->deterministic) return false;          // (the cell sort's ranks come from atomics in arrival order)
     return c->sort_mode == 1 ? true : (c->sort_mode == 0 ? false : ((flags & NSK_GRAD_GRIDS) && !(flags & NSK_GRAD_RAYS) && M >= 2048));
 }
 
@@ -1526,7 +1551,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         if (grids) c->touched[NSK_GROUP_COARSE + w] = true;
         ++n;
     }
-    const int separate = 0;
+    const int separate = c->deterministic ? 1 : 0;      // debug mode: one launch per decoder, in a fixed order
     if ((n == 0 || train_role == -2 || separate) && d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
     if (n == 0) return 0;
     if (train_role == -2 || separate) {      // rare configuration (several trainable decoders share one slab buffer): one launch each

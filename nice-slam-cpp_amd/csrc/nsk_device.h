@@ -1126,9 +1126,10 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     const int kmax = tiles_per_wave(ntasks, nw, tsh);
     stage(tile_of(0, wg, nw, tsh), slot_sample(A, slot_of(tile_of(0, wg, nw, tsh))), nx);
     int mm_next = slot_sample(A, slot_of(tile_of(1, wg, nw, tsh)));
+    const bool det = (A.flags & 0x8000u) != 0;      // deterministic debug mode: every wave walks all kmax rounds (they meet at barriers)
     for (int k = 0; k < kmax; ++k) {
         const int task = tile_of(k, wg, nw, tsh);
-        if (task >= ntasks) break;
+        if (task >= ntasks && !det) break;
         asm volatile("" ::: "memory");      // keep the LDS fragment reads inside the loop (LICM would hoist + spill them)
         const bool valid = task * 16 + j < A.M;
         const int mm = nx.mm;
@@ -1220,7 +1221,8 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             tri_grad_p(A.grid, T, g, gc, gp);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { gp[k] += __shfl_xor(gp[k], 16); gp[k] += __shfl_xor(gp[k], 32); }
-            if (A.g_rays_o) {
+            if (A.g_rays_o) for (int turn = 0; turn < (det ? 8 : 1); ++turn) {
+                if (det) { __syncthreads(); if (turn != wave) continue; }
                 // the 16 samples of a tile usually belong to one ray (S = 48 = 3 tiles): sum them in the wave and add once; sixteen
                 // lanes adding to one address serialise (200 rays: the ray-gradient atomics were most of a 74 us kernel)
                 const int n0 = __builtin_amdgcn_readfirstlane(n);
@@ -1243,10 +1245,13 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                         atomicAdd(A.g_rays_d + 3 * n + k, gp[k] * zz);
                     }
                 }
+                if (det) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
         if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) {
-            scatter_tile(A.grid, T, gc, lane, valid, scratch);
+            if (det) {                      // deterministic debug mode (one workgroup): the waves scatter in turn, so every atomic add has a fixed place in time
+                for (int w = 0; w < 8; ++w) { if (wave == w) { scatter_tile(A.grid, T, gc, lane, valid, scratch); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } __syncthreads(); }
+            } else scatter_tile(A.grid, T, gc, lane, valid, scratch);
         }
     }
 }

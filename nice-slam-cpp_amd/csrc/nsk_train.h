@@ -487,7 +487,11 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             stage_b(nx);
         }
         NSK_PH(17); NSK_PHI(17);
-        if (scat) scatter_tile(A.grid, T, gc, lane, valid, scratch);
+        if (scat) {
+            if (A.flags & 0x8000u) {        // deterministic debug mode: see decode_bwd_body
+                for (int w = 0; w < 8; ++w) { if (wave == w) { scatter_tile(A.grid, T, gc, lane, valid, scratch); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } __syncthreads(); }
+            } else scatter_tile(A.grid, T, gc, lane, valid, scratch);
+        }
         NSK_PH(10); NSK_PHI(10);
     }
     NSK_PH(11);

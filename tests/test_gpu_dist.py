@@ -165,3 +165,24 @@ def test_stale_graph_is_refused_after_the_workspace_grew():
         ctx.graph_launch(gid2)
     ctx.sync()
     assert np.isfinite(ctx.grid_download("fine")).all()
+
+
+def test_deterministic_debug_mode_is_bit_reproducible():
+    """nsk_set_tuning(ctx, "deterministic", 1): ray order, one backward launch per decoder, one workgroup whose waves add in turn -- two
+    runs give bit-identical gradients (the normal mode's differ from run to run in the last bits: floating-point atomics), and they
+    agree with the normal mode's to rounding.  This is the tool for telling a defect from atomic-order sensitivity."""
+    out = {}
+    for mode in ("det_a", "det_b", "normal"):
+        sc, ctx, (ro, rd, gd, gc), mk = _setup(seed=21, masks=False, n=300)
+        if mode != "normal":
+            ctx.set_tuning("deterministic", 1)
+        loss = torch.zeros(1, device="cuda")
+        g_ro = torch.empty_like(ro); g_rd = torch.empty_like(rd)
+        ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.5, True, flags=3, loss=loss)
+        ctx.sync()
+        out[mode] = ({k: ctx.grid_download(k, grad=True) for k in ("middle", "fine", "color")}, ctx.decoder_download("color", grad=True), float(loss))
+    for k in ("middle", "fine", "color"):
+        assert np.array_equal(out["det_a"][0][k], out["det_b"][0][k]), k
+        assert np.abs(out["det_a"][0][k]).max() > 0 and rel_l2(out["det_a"][0][k], out["normal"][0][k]) < 1e-5, k
+    assert np.array_equal(out["det_a"][1], out["det_b"][1]) and rel_l2(out["det_a"][1], out["normal"][1]) < 1e-5
+    assert out["det_a"][2] == out["det_b"][2]

@@ -56,7 +56,7 @@ __global__ void k_adam(int n, float* __restrict__ p, float* __restrict__ g, floa
     *g4 = (f4)(0.f);
 }
 
-struct AdamSeg { float* p; float* g; float* m; float* v; const uint8_t* mask; int n; float step_size, bc2s; int blk_end;
+struct AdamSeg { float* p; float* g; float* m; float* v; const int* idx; int nidx; int n; float step_size, bc2s; int blk_end;      // idx: the marked voxels (nullptr = all)
                  const int* inv_f; const int* inv_b; float* fimg; float* bimg;      // decoders: image position of each parameter (-1 none)
                  const int* inv16; unsigned short* img16; float* img16_tail; int tail_off;
                  const float* slabs; int nslabs, slab_stride; };                      // pending per-workgroup gradient slabs (k_decode_bwd_multi)   // bf16 3-piece image (nsk_bf16.h), its fp32 tail
@@ -83,9 +83,12 @@ __global__ void k_adam_multi(AdamArgs A)
 #pragma unroll
         for (int k = 0; k < 8; ++k) extra += red[k][pi];
     }
+    if (S.idx) {                  // a masked level: the launch covers the marked voxels only (8 float4 each); unmarked ones are never touched
+        if (i >= S.nidx * 8) return;
+        i = S.idx[i >> 3] * 8 + (i & 7);
+    }
     if (4 * i >= S.n) return;
     f4* g4 = reinterpret_cast<f4*>(S.g) + i;
-    if (S.mask && !S.mask[i >> 3]) { *g4 = (f4)(0.f); return; }
     const f4 g0 = *g4;
     f4 gg = g0 + extra, mm = reinterpret_cast<f4*>(S.m)[i], vv = reinterpret_cast<f4*>(S.v)[i];
     // a parameter that never received a gradient (g = m = v = 0) does not move under Adam: skip its five memory operations
@@ -857,7 +860,7 @@ extern "C" int nsk_grid_upload(nsk_ctx* c, int level, const float* h, int C, int
     if (realloc_) {
         HIPCHK(hipStreamSynchronize(c->stream));
         invalidate_graphs(c);
-        hipFree(G.v); hipFree(G.m); hipFree(G.s); hipFree(G.mask); G.mask = nullptr;
+        hipFree(G.v); hipFree(G.m); hipFree(G.s); hipFree(G.mask); G.mask = nullptr; hipFree(G.midx); G.midx = nullptr;
         HIPCHK(hipMalloc(&G.v, n * 4)); HIPCHK(hipMalloc(&G.m, n * 4)); HIPCHK(hipMalloc(&G.s, n * 4));
     }
     if (G.Z != Z || G.Y != Y || G.X != X) { if (G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); invalidate_graphs(c); hipFree(G.mask); G.mask = nullptr; } }
@@ -893,7 +896,16 @@ extern "C" int nsk_grid_download(nsk_ctx* c, int level, float* h)
 extern "C" int nsk_grid_grad_download(nsk_ctx* c, int level, float* h)
 {
     if (!c || !h || !which_ok(level)) return fail("nsk_grid_grad_download: bad argument");
-    return grid_fetch(c, level, c->slab + c->grid[level].g_off, h);
+    CHK(grid_fetch(c, level, c->slab + c->grid[level].g_off, h));
+    GridState& G = c->grid[level];
+    if (G.mask) {                                   // "gradients of unmarked voxels are discarded": what the scatter left there is not a gradient
+        const size_t nvox = G.n / 32;
+        std::vector<uint8_t> m(nvox);
+        HIPCHK(hipMemcpy(m.data(), G.mask, nvox, hipMemcpyDeviceToHost));
+        for (int ch = 0; ch < 32; ++ch)
+            for (size_t v = 0; v < nvox; ++v) if (!m[v]) h[(size_t)ch * nvox + v] = 0.f;
+    }
+    return 0;
 }
 
 extern "C" int nsk_set_mask(nsk_ctx* c, int level, const uint8_t* h_mask)
@@ -904,6 +916,9 @@ extern "C" int nsk_set_mask(nsk_ctx* c, int level, const uint8_t* h_mask)
     HIPCHK(hipStreamSynchronize(c->stream));
     size_t nvox = G.n / 32;
     G.midx_dirty = true;
+    // Unmarked voxels are never visited by the optimiser, so whatever the scatter added to their gradient stays there: a voxel that
+    // becomes marked now must not inherit it.  The level's gradient is cleared whenever its mask changes.
+    if (c->slab) HIPCHK(hipMemsetAsync(c->slab + G.g_off, 0, G.n * 4, c->stream));
     if (!h_mask) { if (G.mask) { invalidate_graphs(c); hipFree(G.mask); G.mask = nullptr; } return 0; }
     if (!G.mask) { invalidate_graphs(c); HIPCHK(hipMalloc(&G.mask, nvox)); }
     HIPCHK(hipMemcpy(G.mask, h_mask, nvox, hipMemcpyHostToDevice));
@@ -1038,6 +1053,7 @@ static int repack(nsk_ctx* c, int w)
 }
 
 static int flush_pending(nsk_ctx* c);
+static int ensure_midx(nsk_ctx* c, int l);
 static void adam_consts(float lr, float b1, float b2, int step, float& step_size, float& bc2s);
 
 extern "C" size_t nsk_decoder_param_count(int which) { return which_ok(which) ? (size_t)nsk_dec_layout(which).total : 0; }
@@ -1737,6 +1753,7 @@ extern "C" int nsk_frustum_mask(nsk_ctx* c, int level, const float* d_depth, int
     HIPCHK(hipSetDevice(c->device));
     const size_t nvox = G.n / 32;
     G.midx_dirty = true;
+    if (c->slab) HIPCHK(hipMemsetAsync(c->slab + G.g_off, 0, G.n * 4, c->stream));       // see nsk_set_mask
     if (!G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); invalidate_graphs(c); HIPCHK(hipMalloc(&G.mask, nvox)); }
     if (level == NSK_COARSE) {                                   // src/Mapper.cpp:54-59
         HIPCHK(hipMemsetAsync(G.mask, 1, nvox, c->stream));
@@ -1914,8 +1931,10 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
         seg_group[AA.n] = grp;
         AdamSeg& S = AA.s[AA.n++];
         adam_consts(lr[grp], b1, b2, step, S.step_size, S.bc2s);
-        S.p = G.v; S.g = c->slab + G.g_off; S.m = G.m; S.v = G.s; S.mask = G.mask; S.n = (int)G.n;
-        blocks += ((int)G.n / 4 + 255) / 256; S.blk_end = blocks;
+        CHK(ensure_midx(c, lv));
+        S.p = G.v; S.g = c->slab + G.g_off; S.m = G.m; S.v = G.s; S.n = (int)G.n;
+        S.idx = G.mask ? G.midx : nullptr; S.nidx = G.mask ? G.nmask : 0;
+        blocks += G.mask ? std::max(1, (G.nmask * 8 + 255) / 256) : ((int)G.n / 4 + 255) / 256; S.blk_end = blocks;
         c->touched[grp] = false;
     }
     if (c->touched[NSK_GROUP_DECODERS]) {
@@ -1928,7 +1947,7 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
             seg_group[AA.n] = NSK_GROUP_DECODERS;
             AdamSeg& S = AA.s[AA.n++];
             adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, S.step_size, S.bc2s);
-            S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.mask = nullptr; S.n = n4;
+            S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.idx = nullptr; S.nidx = 0; S.n = n4;
             S.inv_f = D.finv; S.inv_b = D.binv; S.fimg = D.fimg; S.bimg = D.bimg;
             D.bimg16_dirty = true;
             if (c->pend_w == w) {
@@ -2073,6 +2092,22 @@ extern "C" int nsk_grad_slab(nsk_ctx* c, float** p, size_t* n)
     return 0;
 }
 
+// ascending list of a level's marked voxels (used by the optimiser launch and by the packed exchange); rebuilt when the mask changed
+static int ensure_midx(nsk_ctx* c, int l)
+{
+    GridState& G = c->grid[l];
+    if (!G.mask || !G.midx_dirty) return 0;
+    if (c->capturing) return fail("graph capture: a mask changed since the last eager step (run the step once after installing masks, then capture)");
+    const int nvox = (int)(G.n / 32);
+    if (!G.midx) HIPCHK(hipMalloc(&G.midx, (size_t)nvox * 4));
+    int* d_count = reinterpret_cast<int*>(c->scal + 8);
+    k_mask_index<<<1, 1024, 0, c->stream>>>(nvox, G.mask, G.midx, d_count);
+    HIPCHK(hipMemcpyAsync(&G.nmask, d_count, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                 // once per mask, not per step
+    G.midx_dirty = false;
+    return 0;
+}
+
 // Which parts of the slab a step's exchange must carry: the grid levels and trainable decoders that received gradients since the
 // last optimiser step (the same on every rank: it follows from the stage and the flags) and the loss scalars.
 static int pack_layout(nsk_ctx* c, size_t* total)
@@ -2082,15 +2117,7 @@ static int pack_layout(nsk_ctx* c, size_t* total)
         GridState& G = c->grid[l];
         c->xlevels[l] = G.n && c->touched[NSK_GROUP_COARSE + l];
         if (!c->xlevels[l]) continue;
-        if (G.mask && G.midx_dirty) {
-            const int nvox = (int)(G.n / 32);
-            if (!G.midx) HIPCHK(hipMalloc(&G.midx, (size_t)nvox * 4));
-            int* d_count = reinterpret_cast<int*>(c->scal + 8);
-            k_mask_index<<<1, 1024, 0, c->stream>>>(nvox, G.mask, G.midx, d_count);
-            HIPCHK(hipMemcpyAsync(&G.nmask, d_count, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));                 // once per mask, not per step
-            G.midx_dirty = false;
-        }
+        CHK(ensure_midx(c, l));
         n += (size_t)(G.mask ? G.nmask : (int)(G.n / 32)) * 32;
     }
     for (int w = 0; w < 4; ++w) {

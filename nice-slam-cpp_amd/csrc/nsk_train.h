@@ -12,10 +12,14 @@
 #include <type_traits>
 
 #define PN_LD 132                     // panel row stride in floats (128 samples + 4 pad)
-#define PN_GROWS 32                   // rows 0..31: G, rows 32..63: a 32-row X (c, h), rows 64..159: a 96-row X (e, g_s)
-// e is written to rows PN_EROWS(CQ).. once per iteration, in the forward recompute, and read by W3 and W0 (behind the 16*CQ rows of c)
-#define PN_EROWS(CQ) (PN_GROWS + 16 * (CQ))
-#define PN_FLOATS(CQ) ((PN_EROWS(CQ) + 96) * PN_LD)   // CQ = 2: 160 rows = 84480 B; rows 0..63 double as the per-wave scatter scratch
+#define PN_GROWS 32                   // rows 0..31: G; rows 32..63: a 32-row X (h of the W phases); rows 64..156: e (then g_s), 93 rows; rows 157..: c
+// e is written to rows PN_EROWS.. once per iteration and read by W3 and W0; the grid features c follow it at PN_CROWS and stay
+// resident for the five FC phases (they used to be re-transposed into the X rows in each of them).  The e region is 93 rows, not 96:
+// its last 16-row chunk runs three rows into c, which only feeds output columns 93..95 that pn_flush never stores; and the three zero
+// pad rows of an e (or g_s) write land on c rows 0..2, so e is written BEFORE c at the top of an iteration and g_s after c's last use.
+#define PN_EROWS(CQ) (PN_GROWS + 32)
+#define PN_CROWS(CQ) (PN_EROWS(CQ) + 93)
+#define PN_FLOATS(CQ) ((PN_CROWS(CQ) + 16 * (CQ)) * PN_LD)   // CQ = 2: 189 rows = 99792 B (+ 63104 B backward image <= 160 KiB); rows 0..63 double as the per-wave scatter scratch
 
 // one phase = one (G, X) pair: RT row tiles of G, NC 16-row chunks of X, optional row sums (bias gradients)
 struct TrainPhase {
@@ -300,6 +304,8 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             embed<false>(Bm, g, px, py, pz, C.xe, xcos);     // cos is recomputed after the chain (24 fewer live registers)
 #pragma unroll
             for (int q = 0; q < 6; ++q) pn_put(pn, PN_EROWS(CQ) + 16 * q, wave, lane, C.xe[q]);     // X of phases W3 and W0; xe is dead from here
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) pn_put(pn, PN_CROWS(CQ) + 16 * q, wave, lane, C.xc[q]);    // X of the five FC phases (after e: see PN_CROWS)
             if constexpr (SAVED) { C.h[4][0] = nx.h4[0]; C.h[4][1] = nx.h4[1]; mask = nx.mask; }
             else { mlp_forward<CQ>(fimg, lane, C); mask = C.mask; }
         } else {
@@ -348,11 +354,9 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 // ---- phase FC_l: G = g_h, X = c ------------------------------------------------------------
                 if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, gh[0]);
                 if (!NSK_DBG(A, 14)) pn_put(pn, 16, wave, lane, gh[1]);
-#pragma unroll
-                for (int q = 0; q < CQ; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16 * q, wave, lane, C.xc[q]);
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_FC0 + l];
-                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PN_CROWS(CQ));
                 NSK_BAR();
             }
             if constexpr (l == 3) NSK_PH(13); NSK_PHI(13);

@@ -88,7 +88,13 @@ def _mapping_steps_vs_oracle(ctx, o, sc, rays, stage, steps, w_color=0.5, masks=
         l_ref, bw = _oracle_grads(o, sc, grids, decs, rays, stage, w_color, gmax)
         bw64 = _oracle_grads(o64, sc, grids, decs, rays, stage, w_color, gmax)[1] if o64 is not None else None
         assert abs(float(loss_t) - l_ref) < 2e-5 * abs(l_ref), (step, float(loss_t), l_ref)
-        pairs = [("grid_" + k, g_gpu[k], bw["g_grids"][k], bw64["g_grids"][k] if bw64 else None) for k in levels]
+        # with optimiser masks the parameter is grid[mask] (src/Mapper.cpp:297-317: the masked part is the autograd leaf), so the
+        # gradient exists at marked voxels only; nsk_grid_grad_download returns zeros elsewhere
+        vmask = (lambda k, g: g) if masks is None else (lambda k, g: g * masks[k][None])
+        pairs = [("grid_" + k, g_gpu[k], vmask(k, bw["g_grids"][k]), vmask(k, bw64["g_grids"][k]) if bw64 else None) for k in levels]
+        if masks is not None:
+            for k in levels:
+                assert not g_gpu[k][:, ~masks[k]].any()
         if stage == "color":
             pairs.append(("colour decoder", gdec_gpu, bw["g_decoders"]["color"], bw64["g_decoders"]["color"] if bw64 else None))
         for name, got_g, ref_g, ref64_g in pairs:

@@ -170,6 +170,9 @@ def cpu_baseline_aten(sc, rays_list, stage, lr, w_color, seconds):
             "ms_per_step": 1e3 * dt / steps}
 
 
+TUNE = []
+
+
 def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, frustum=True):
     """time `steps` mapping iterations of workload `wl` at `N` rays per GPU; returns dict(dt, prof, loss, scene, pool)"""
     import nice_slam_cpp_amd as pkg
@@ -182,6 +185,9 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
     # those frames every iteration (src/Mapper.cpp:376-414); every rank draws its own pixels of the same frames
     pool = [scenes.make_rays(1234 + 17 * i + 1000 * rank, N, sc["bound"], n_frames=5, cam_seed=4242, up=wl["up"], **cam) for i in range(8)]
     ctx = pkg.Context(local)
+    for kv in TUNE:                                  # --tune key=value: nsk_set_tuning experiments (include/nsk.h)
+        k, v = kv.split("=")
+        ctx.set_tuning(k, int(v))
     ctx.set_render_opts()                                        # 32 + 16 samples (src/Renderer.cpp:9-10)
     ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
     mask_frac = None
@@ -297,8 +303,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the K2 / fine-stage / K4-shard lines under 'extras'")
     ap.add_argument("--no-frustum-mask", action="store_true", help="optimise every voxel (mapping.frustum_feature_selection: False)")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step as a captured hipGraph (single GPU)")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for nsk_set_tuning (experiments), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of each CPU baseline's timed sample")
     args = ap.parse_args()
+    TUNE[:] = args.tune
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -628,6 +628,7 @@ struct nsk_ctx {
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     bool deterministic = false;             // debug: bit-reproducible gradients (see nsk_set_tuning in include/nsk.h)
     bool roctx = false;                     // roctx ranges around every profiled launch group (libroctx64, loaded on demand)
+    int tune_skew = 0;                      // start offset of the upper four waves of a decoder workgroup, x 1024 cycles (wave_skew, nsk_device.h)
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
@@ -790,6 +791,7 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
 {
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
+    if (!strcmp(key, "skew")) { if (value < 0 || value > 299) return fail("nsk_set_tuning: skew out of range"); c->tune_skew = value; return 0; }
     if (!strcmp(key, "deterministic")) { c->deterministic = value != 0; return 0; }
     if (!strcmp(key, "roctx")) { c->roctx = value != 0; return 0; }
     return fail("nsk_set_tuning: unknown key '%s'", key);
@@ -1239,6 +1241,7 @@ static void fill_args(nsk_ctx* c, DecArgs& A, int w, int M, int S, const float* 
     A.img16 = c->dec[w].fimg16;
     A.bimg16 = c->dec[w].bimg16;
     A.out = w == 3 ? c->ws.rgb4 : c->ws.occ[w];
+    A.skew = c->tune_skew;
 }
 
 static int launch_decode_fwd(nsk_ctx* c, int w, int M, int S, const float* ro, const float* rd, const float* pts, bool save_masks)
@@ -1562,7 +1565,8 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         const int frozen_cost = c->tune_frozen_cost > 0 ? c->tune_frozen_cost : 190;
         cost[n] = train ? 1000 : frozen_cost;
         lds = std::max(lds, bwd_lds_bytes(w, train));
-        if (train) train_role = train_role == -1 ? n : -2;     // -2: more than one trainable decoder -> separate launches below
+        if (train) train_role = (train_role == -1 && w != 2) ? n : -2;     // -2: more than one trainable decoder, or the fine one (its
+                                                                            // body is not part of k_decode_bwd_multi) -> separate launches below
         if (train) c->touched[NSK_GROUP_DECODERS] = true;
         if (grids) c->touched[NSK_GROUP_COARSE + w] = true;
         ++n;

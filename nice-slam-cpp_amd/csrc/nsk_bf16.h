@@ -143,6 +143,7 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
     int m = slot_sample(A, tile_of(0, wg, nw, tsh) * 16 + j);
     sample_load(A, m, nx);
     int m_next = slot_sample(A, tile_of(1, wg, nw, tsh) * 16 + j);
+    wave_skew(A, wave, NW);
     for (int k = 0; k < kmax; ++k) {
         const int task = tile_of(k, wg, nw, tsh);
         if (task >= ntasks) break;

@@ -489,52 +489,24 @@ struct Act {               // activations of one 16-sample tile, D layout
     unsigned long long mask;   // ReLU bits, layer l -> bits 8l..8l+7
 };
 
-// sin / cos with a 3-term Cody-Waite reduction by pi using FMA (each product is exact inside the FMA) and ONE
-// near-minimax polynomial each on [-pi/2, pi/2]: max abs error 1.4e-7 for |x| < 1e4 (arguments here are
-// |p| * 25 * N(0,1) ~ 1e2).  The library sinf carries a Payne-Hanek path (~100 VALU instructions per call); VALU
-// instructions share the SIMD's fp32 pipe with the fp32 MFMAs, so every one of them adds to the kernel time.
-__device__ __forceinline__ float nsk_reduce_pi(float x, int& k_out)
+// sin / cos on the hardware's v_sin_f32 / v_cos_f32, which take the argument in revolutions.  Measured on gfx950 over 4 M arguments
+// in [-0.5, 0.5] rev (tools/ubench/vsin.hip): max abs error 1.25e-7 for both.  The argument is reduced in revolutions with a two-term
+// split of 1/(2 pi): fma(x, HI, -k) is one rounding of the exact x*HI - k (k <= a few hundred here: |p| * 25 * N(0,1) ~ 1e2), so the
+// reduced argument carries at most half an ulp of 0.5 rev = 1.9e-7 rad.  A polynomial sine on the vector ALU costs 15 instructions per
+// value against 4 + one quarter-rate transcendental here, and vector instructions do not overlap the bf16 MFMAs of the other wave on a
+// SIMD (tools/ubench/interleave.hip), so they add to the kernel time one for one.  (The library sinf carries a Payne-Hanek path.)
+__device__ __forceinline__ float nsk_rev(float x)
 {
-    const float k = rintf(x * 0.318309886f);                 // 1/pi
-    float r = fmaf(k, -3.14159250259399414062f, x);          // pi split: 0x1.921fb4p+1
-    r = fmaf(k, -1.50995788317231927067e-07f, r);            //           0x1.4442d0p-23
-    r = fmaf(k, -1.07806050599155295e-14f, r);               //           0x1.846988p-47
-    k_out = (int)k;
-    return r;
+    const float k = rintf(x * 0.15915494309189535f);
+    const float f = fmaf(x, 0.159154936671257019f, -k);      // 1/(2 pi) split: 0x1.45f306p-3
+    return fmaf(x, 6.42063833e-09f, f);                      //                  + 0x1.b9391p-28
 }
-__device__ __forceinline__ float nsk_sin_poly(float r, float u)
-{
-    float p = fmaf(-2.3866771670100206e-08f, u, 2.752401314864983e-06f);
-    p = fmaf(p, u, -0.00019840836466755718f);
-    p = fmaf(p, u, 0.008333330973982811f);
-    p = fmaf(p, u, -0.1666666716337204f);
-    p = fmaf(p, u, 1.0f);
-    return r * p;
-}
-__device__ __forceinline__ float nsk_cos_poly(float u)
-{
-    float q = fmaf(1.9888739544171585e-09f, u, -2.752338446043723e-07f);
-    q = fmaf(q, u, 2.4801007384667173e-05f);
-    q = fmaf(q, u, -0.0013888883404433727f);
-    q = fmaf(q, u, 0.0416666679084301f);
-    q = fmaf(q, u, -0.5f);
-    return fmaf(q, u, 1.0f);
-}
-__device__ __forceinline__ float nsk_sin(float x)
-{
-    int k;
-    const float r = nsk_reduce_pi(x, k);
-    const float s = nsk_sin_poly(r, r * r);
-    return __int_as_float(__float_as_int(s) ^ (k << 31));    // (-1)^k
-}
+__device__ __forceinline__ float nsk_sin(float x) { return __builtin_amdgcn_sinf(nsk_rev(x)); }
 __device__ __forceinline__ void nsk_sincos(float x, float& sn, float& cs)
 {
-    int k;
-    const float r = nsk_reduce_pi(x, k);
-    const float u = r * r;
-    const int sg = k << 31;
-    sn = __int_as_float(__float_as_int(nsk_sin_poly(r, u)) ^ sg);
-    cs = __int_as_float(__float_as_int(nsk_cos_poly(u)) ^ sg);
+    const float f = nsk_rev(x);
+    sn = __builtin_amdgcn_sinf(f);
+    cs = __builtin_amdgcn_cosf(f);
 }
 
 // embedding e = sin(p B) (reference src/models/GaussianFFT.cpp:10-15), optional cos for the backward
@@ -658,7 +630,20 @@ struct DecArgs {
     float* g_rays_o; float* g_rays_d;    // [N][3] accumulated with atomics, or nullptr
     float* g_dec;             // canonical decoder gradient (trainable) or nullptr
     unsigned flags;
+    int skew;                 // start offset of a workgroup's upper four waves, in units of 1024 cycles (wave_skew)
 };
+
+// The two waves that share a SIMD (w and w + 4 of a 512-thread workgroup) start a kernel in step, and a tile is a long vector-unit
+// phase (sample, gather, embedding, operand split) followed by a long matrix-core phase; in step they queue on the same unit in
+// both phases while the other unit idles (counters: MFMA busy 28 %, VALU 55 %, co-execution 11 % of the MFMA cycles).  Holding the
+// upper four waves back once, by about one vector phase, lets one wave's MFMA chain run under the other's vector work from then on.
+__device__ __forceinline__ void wave_skew(const DecArgs& A, int wave, int nw)
+{
+    const int mode = A.skew / 100, n = A.skew % 100;
+    const bool late = mode == 0 ? wave >= nw / 2 : (mode == 1 ? (wave & 1) : ((wave >> 1) & 1));
+    if (late)
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
 
 __device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px, float& py, float& pz, float& zz, int& n)
 {
@@ -1127,6 +1112,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     stage(tile_of(0, wg, nw, tsh), slot_sample(A, slot_of(tile_of(0, wg, nw, tsh))), nx);
     int mm_next = slot_sample(A, slot_of(tile_of(1, wg, nw, tsh)));
     const bool det = (A.flags & 0x8000u) != 0;      // deterministic debug mode: every wave walks all kmax rounds (they meet at barriers)
+    if (!det) wave_skew(A, wave, 8);
     for (int k = 0; k < kmax; ++k) {
         const int task = tile_of(k, wg, nw, tsh);
         if (task >= ntasks && !det) break;

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
     case 2: decode_bwd_body<1, RAYS>(MA.a[r], bid, nb); break;
     case 3: decode_bwd_train_body<1, RAYS>(MA.a[r], bid, nb); break;
     case 4: decode_bwd_body<2, RAYS>(MA.a[r], bid, nb); break;
-    case 5: decode_bwd_train_body<2, RAYS>(MA.a[r], bid, nb); break;
+    case 5: break;     // trainable fine decoder (64-wide c: 1.4 KB of scratch per lane): launched on its own as k_decode_bwd_train<2>, never here
     case 6: decode_bwd_body<3, RAYS>(MA.a[r], bid, nb); break;
     default: decode_bwd_train_body<3, RAYS>(MA.a[r], bid, nb); break;
     }

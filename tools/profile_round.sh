@@ -9,7 +9,10 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 $R/bench.py --steps 50 --warmup 5 --cpu-seconds 8 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+# --no-extras: the extra workloads launch the same kernels on other shapes, and the per-kernel averages must be the headline workload's
+timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 $R/bench.py --steps 200 --warmup 20 --cpu-seconds 8 --no-extras > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+# the default command, unprofiled (headline + extras + both CPU baselines)
+timeout -k 10 420 python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 cp $OUT/stats/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 BARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-extras"
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -11,15 +11,15 @@
 #include "nsk_device.h"
 #include <type_traits>
 
-#define PN_LD 132                     // panel row stride in floats (128 samples + 4 pad)
-#define PN_GROWS 32                   // rows 0..31: G; rows 32..63: a 32-row X (h of the W phases); rows 64..156: e (then g_s), 93 rows; rows 157..: c
-// e is written to rows PN_EROWS.. once per iteration and read by W3 and W0; the grid features c follow it at PN_CROWS and stay
-// resident for the five FC phases (they used to be re-transposed into the X rows in each of them).  The e region is 93 rows, not 96:
-// its last 16-row chunk runs three rows into c, which only feeds output columns 93..95 that pn_flush never stores; and the three zero
-// pad rows of an e (or g_s) write land on c rows 0..2, so e is written BEFORE c at the top of an iteration and g_s after c's last use.
-#define PN_EROWS(CQ) (PN_GROWS + 32)
-#define PN_CROWS(CQ) (PN_EROWS(CQ) + 93)
-#define PN_FLOATS(CQ) ((PN_CROWS(CQ) + 16 * (CQ)) * PN_LD)   // CQ = 2: 189 rows = 99792 B (+ 63104 B backward image <= 160 KiB); rows 0..63 double as the per-wave scatter scratch
+// The panel holds every element as its two leading bf16 pieces, h = bf16(x) and m = bf16(x - h), in two PLANES of 16-bit values:
+// plane H at the panel base, plane M PN_MOFF(CQ) bytes behind it, rows of 128 samples (256 B) + 16 B pad.  The pad makes a row step
+// four banks, so the 16-row b128 operand reads and the 4-row b16 transposing writes are both conflict-free.
+#define PN_RB 272                     // bytes per plane row
+#define PN_GROWS 32                   // rows 0..31: G; then 16*CQ rows of X (c in the FC phases, h in the W phases); then 96 rows of e (later g_s)
+#define PN_EROWS(CQ) (PN_GROWS + 16 * (CQ))
+#define PN_ROWS(CQ) (PN_EROWS(CQ) + 96)
+#define PN_MOFF(CQ) (PN_ROWS(CQ) * PN_RB)
+#define PN_FLOATS(CQ) (2 * PN_MOFF(CQ) / 4)          // CQ = 2: 160 rows x 2 planes = 87040 B (+ 63104 B backward image <= 160 KiB); its head doubles as the per-wave scatter scratch
 
 // one phase = one (G, X) pair: RT row tiles of G, NC 16-row chunks of X, optional row sums (bias gradients)
 struct TrainPhase {
@@ -91,41 +91,42 @@ __global__ void k_dec_grad_reduce(int n, int n4, int nslabs, const float* __rest
     if (acc != 0.f) atomicAdd(g + i, acc);
 }
 
-// Panel words.  A panel element is not the fp32 value but its two leading bf16 pieces packed into one 32-bit word,
-// low half h = bf16(x), high half m = bf16(x - h): x = h + m to 2^-17 relative (16 significant bits).  A lane's four consecutive
-// samples are then eight bf16 operand slots (h0 m0 h1 m1 ...) of v_mfma_f32_16x16x32_bf16, and
-//     mfma(A, B) + mfma(A, B with the halves of every word swapped) = sum_s (hA + mA)(hB + mB)
-// i.e. two bf16 matrix instructions (2 x 16 cycles) contract 16 samples where the fp32 form needs four v_mfma_f32_16x16x4_f32
-// (4 x 32 cycles, during which the SIMD issues no vector instruction).  Products carry 2^-17 relative rounding each, sums stay
+// Panel operands.  A lane's eight consecutive samples of one plane are the eight bf16 operand slots of v_mfma_f32_16x16x32_bf16, so
+//     mfma(A_h, B_h) + mfma(A_m, B_m) + mfma(A_h, B_m) + mfma(A_m, B_h) = sum over 32 samples of (hA + mA)(hB + mB)
+// i.e. four bf16 matrix instructions (4 x 16 cycles) contract 32 samples where the fp32 form needs eight v_mfma_f32_16x16x4_f32
+// (8 x 32 cycles, during which the SIMD issues no vector instruction).  Products carry 2^-17 relative rounding each, sums stay
 // fp32: measured against the fp64 oracle the weight gradients are as close as the fp32 ones (tests/test_gpu_parity.py).
-// The panel's layout and addressing are those of an fp32 panel.
+// (Until round 2 the two pieces shared a 32-bit word: that form needs the halves of every B word swapped for the cross products --
+// four v_alignbit per operand read, 12 % of this role's vector instructions -- and four more to merge the halves when packing.)
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pack2_pair(float x0, float x1, unsigned& w0, unsigned& w1)
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h01, unsigned& m01)
 {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
-    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){x0, x1}, bf2));
+    h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){x0, x1}, bf2));
     const float r0 = x0 - __uint_as_float(h01 << 16), r1 = x1 - __uint_as_float(h01 & 0xffff0000u);
-    const unsigned m01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){r0, r1}, bf2));
-    w0 = (h01 & 0xffffu) | (m01 << 16);
-    w1 = (h01 >> 16) | (m01 & 0xffff0000u);
+    m01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){r0, r1}, bf2));
 }
 
-// transpose one D-layout quad (16 feature rows x this wave's 16 samples) into the panel at row `row0`
-__device__ __forceinline__ void pn_put(float* __restrict__ pn, int row0, int wave, int lane, f4 x)
+// transpose one D-layout quad (16 feature rows x this wave's 16 samples) into the panel at row `row0`: 16-bit stores (low / high half)
+__device__ __forceinline__ void pn_put(char* __restrict__ pn, int moff, int row0, int wave, int lane, f4 x)
 {
     const int j = lane & 15, g = lane >> 4;
-    unsigned* pw = reinterpret_cast<unsigned*>(pn);
-    unsigned w[4];
-    pack2_pair(x[0], x[1], w[0], w[1]);
-    pack2_pair(x[2], x[3], w[2], w[3]);
+    char* ph = pn + (row0 + 4 * g) * PN_RB + (16 * wave + j) * 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pw[(row0 + 4 * g + i) * PN_LD + 16 * wave + j] = w[i];
+    for (int p = 0; p < 2; ++p) {
+        unsigned h01, m01;
+        split2_pair(x[2 * p], x[2 * p + 1], h01, m01);
+        *reinterpret_cast<unsigned short*>(ph + (2 * p) * PN_RB) = (unsigned short)h01;
+        *reinterpret_cast<unsigned short*>(ph + (2 * p + 1) * PN_RB) = (unsigned short)(h01 >> 16);
+        *reinterpret_cast<unsigned short*>(ph + moff + (2 * p) * PN_RB) = (unsigned short)m01;
+        *reinterpret_cast<unsigned short*>(ph + moff + (2 * p + 1) * PN_RB) = (unsigned short)(m01 >> 16);
+    }
 }
 
 // the tiles of one phase owned by this wave, accumulated over the panel's 128 samples
 template <int NSL>
-__device__ __forceinline__ void pn_tiles(const float* __restrict__ pn, int RT, int NC, int rowsum, int wave, int lane, f4* acc, int xrow0 = PN_GROWS)
+__device__ __forceinline__ void pn_tiles(const char* __restrict__ pn, int moff, int RT, int NC, int rowsum, int wave, int lane, f4* acc, int xrow0 = PN_GROWS)
 {
     const int r = lane & 15, sq = lane >> 4;
     const int ntiles = RT * NC + (rowsum ? RT : 0);
@@ -136,27 +137,24 @@ __device__ __forceinline__ void pn_tiles(const float* __restrict__ pn, int RT, i
             const bool rs = tile >= RT * NC;
             const int rt = rs ? tile - RT * NC : tile / NC;
             const int ch = rs ? 0 : tile % NC;
-            const float* ga = pn + (16 * rt + r) * PN_LD + 4 * sq;
-            const float* xb = pn + (xrow0 + 16 * ch + r) * PN_LD + 4 * sq;
+            const char* ga = pn + (16 * rt + r) * PN_RB + 16 * sq;
+            const char* xb = pn + (xrow0 + 16 * ch + r) * PN_RB + 16 * sq;
             f4 d0 = acc[k], d1 = (f4)(0.f);
 #pragma unroll
-            for (int b = 0; b < 8; b += 2) {
-                const u4v a0 = *reinterpret_cast<const u4v*>(ga + 16 * b);
-                const u4v a1 = *reinterpret_cast<const u4v*>(ga + 16 * b + 16);
+            for (int b = 0; b < 4; ++b) {                   // 32 samples per step
+                const bf8 ah = *reinterpret_cast<const bf8*>(ga + 64 * b);
+                const bf8 am = *reinterpret_cast<const bf8*>(ga + moff + 64 * b);
                 if (rs) {                                   // row sums (bias gradients): every operand slot of B is 1.0
-                    const u4v one = (u4v)(0x3f803f80u);
-                    d0 = mfma_b(__builtin_bit_cast(bf8, a0), __builtin_bit_cast(bf8, one), d0);
-                    d1 = mfma_b(__builtin_bit_cast(bf8, a1), __builtin_bit_cast(bf8, one), d1);
+                    const bf8 one = __builtin_bit_cast(bf8, (u4v)(0x3f803f80u));
+                    d0 = mfma_b(ah, one, d0);
+                    d1 = mfma_b(am, one, d1);
                 } else {
-                    const u4v x0 = *reinterpret_cast<const u4v*>(xb + 16 * b);
-                    const u4v x1 = *reinterpret_cast<const u4v*>(xb + 16 * b + 16);
-                    u4v y0, y1;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { y0[i] = __builtin_amdgcn_alignbit(x0[i], x0[i], 16); y1[i] = __builtin_amdgcn_alignbit(x1[i], x1[i], 16); }
-                    d0 = mfma_b(__builtin_bit_cast(bf8, a0), __builtin_bit_cast(bf8, x0), d0);
-                    d1 = mfma_b(__builtin_bit_cast(bf8, a1), __builtin_bit_cast(bf8, x1), d1);
-                    d0 = mfma_b(__builtin_bit_cast(bf8, a0), __builtin_bit_cast(bf8, y0), d0);
-                    d1 = mfma_b(__builtin_bit_cast(bf8, a1), __builtin_bit_cast(bf8, y1), d1);
+                    const bf8 xh = *reinterpret_cast<const bf8*>(xb + 64 * b);
+                    const bf8 xm = *reinterpret_cast<const bf8*>(xb + moff + 64 * b);
+                    d0 = mfma_b(ah, xh, d0);
+                    d1 = mfma_b(am, xm, d1);
+                    d0 = mfma_b(ah, xm, d0);
+                    d1 = mfma_b(am, xh, d1);
                 }
             }
             acc[k] = d0 + d1;
@@ -204,11 +202,8 @@ __device__ unsigned long long nsk_dbg_ph[8][8][96];      // [workgroup < 8][wave
 // workgroup barrier for LDS data only: __syncthreads() also drains vmcnt, i.e. every outstanding global load, store and
 // atomic of the wave (an atomic stays counted for thousands of cycles), although nothing in global memory is exchanged here
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#ifdef NSK_EXPERIMENT
-#define NSK_BAR() do { if (!NSK_DBG(A, 12)) lds_barrier(); } while (0)
-#else
+// (no experiment switch removes these barriers: the scatter's run table shares LDS with the panel, and a run without them faulted the GPU)
 #define NSK_BAR() lds_barrier()
-#endif
 
 template <int WHICH, bool RAYS>
 __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid, int nb)
@@ -228,8 +223,9 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
-    float* pn = smf + IMG_F;                        // shared panel
-    float* scratch = pn + wave * 1056;              // per-wave scatter scratch (NSK_SCRATCH_FLOATS <= 1056): panel rows 0..63, idle between the last phase and phase OUT
+    char* pn = reinterpret_cast<char*>(smf + IMG_F);     // shared panel (plane H; plane M at + PM)
+    constexpr int PM = PN_MOFF(CQ);
+    float* scratch = smf + IMG_F + wave * 1056;     // per-wave scatter scratch (NSK_SCRATCH_FLOATS <= 1056): the head of plane H, idle between the last phase and phase OUT
     for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.bimg[i];
     __syncthreads();
     const f4* fimg = A.img;                         // !SAVED only: forward fragments from L2
@@ -282,7 +278,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
         NSK_PH(0); NSK_PHI(0);
-        if (it > 0) lds_barrier();                   // panel rows 0..63 were the waves' scatter scratch until here
+        if (it > 0) lds_barrier();                   // the head of the panel was the waves' scatter scratch until here
         const bool valid = nx.valid;
         float px = nx.px, py = nx.py, pz = nx.pz, zz = nx.zz; const int n = nx.n;
         Tri T;
@@ -303,9 +299,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             for (int q = 0; q < CQ; ++q) C.xc[q] = nx.xc[q];
             embed<false>(Bm, g, px, py, pz, C.xe, xcos);     // cos is recomputed after the chain (24 fewer live registers)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) pn_put(pn, PN_EROWS(CQ) + 16 * q, wave, lane, C.xe[q]);     // X of phases W3 and W0; xe is dead from here
-#pragma unroll
-            for (int q = 0; q < CQ; ++q) pn_put(pn, PN_CROWS(CQ) + 16 * q, wave, lane, C.xc[q]);    // X of the five FC phases (after e: see PN_CROWS)
+            for (int q = 0; q < 6; ++q) pn_put(pn, PM, PN_EROWS(CQ) + 16 * q, wave, lane, C.xe[q]);     // X of phases W3 and W0; xe is dead from here
             if constexpr (SAVED) { C.h[4][0] = nx.h4[0]; C.h[4][1] = nx.h4[1]; mask = nx.mask; }
             else { mlp_forward<CQ>(fimg, lane, C); mask = C.mask; }
         } else {
@@ -328,13 +322,13 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             f4 go;
 #pragma unroll
             for (int i = 0; i < 4; ++i) go[i] = (4 * g + i) < OD ? gout[(4 * g + i) < OD ? (4 * g + i) : 0] : 0.f;
-            if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, go);
+            if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, go);
             const f4* h4 = XYZ ? C.h[4] : CC.h[4];
-            if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, h4[0]);
-            if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16, wave, lane, h4[1]);
+            if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS, wave, lane, h4[0]);
+            if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16, wave, lane, h4[1]);
             NSK_BAR();
             constexpr TrainPhase P = plan.p[PL::P_OUT];
-            if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+            if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
             NSK_BAR();
         }
         NSK_PH(2); NSK_PHI(2);
@@ -352,11 +346,13 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             if constexpr (XYZ) {
                 gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);                 // g_c += fc[l]^T g_h
                 // ---- phase FC_l: G = g_h, X = c ------------------------------------------------------------
-                if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, gh[0]);
-                if (!NSK_DBG(A, 14)) pn_put(pn, 16, wave, lane, gh[1]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, gh[0]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 16, wave, lane, gh[1]);
+#pragma unroll
+                for (int q = 0; q < CQ; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16 * q, wave, lane, C.xc[q]);
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_FC0 + l];
-                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PN_CROWS(CQ));
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
                 NSK_BAR();
             }
             if constexpr (l == 3) NSK_PH(13); NSK_PHI(13);
@@ -367,31 +363,31 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
             // ---- phase W_l: G = g_a, X = layer input ----------------------------------------------------------
             {
-                if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, ga[0]);
-                if (!NSK_DBG(A, 14)) pn_put(pn, 16, wave, lane, ga[1]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, ga[0]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 16, wave, lane, ga[1]);
                 if constexpr (XYZ) {
                     if constexpr (l == 0 || l == 3) {
                     } else {
-                        if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, C.h[l - 1][0]);
-                        if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16, wave, lane, C.h[l - 1][1]);
+                        if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS, wave, lane, C.h[l - 1][0]);
+                        if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16, wave, lane, C.h[l - 1][1]);
                     }
                 } else {
-                    if constexpr (l == 0 || l == 3) { pn_put(pn, PN_GROWS, wave, lane, CC.xc[0]); pn_put(pn, PN_GROWS + 16, wave, lane, CC.xc[1]); }
-                    else { pn_put(pn, PN_GROWS, wave, lane, CC.h[l - 1][0]); pn_put(pn, PN_GROWS + 16, wave, lane, CC.h[l - 1][1]); }
+                    if constexpr (l == 0 || l == 3) { pn_put(pn, PM, PN_GROWS, wave, lane, CC.xc[0]); pn_put(pn, PM, PN_GROWS + 16, wave, lane, CC.xc[1]); }
+                    else { pn_put(pn, PM, PN_GROWS, wave, lane, CC.h[l - 1][0]); pn_put(pn, PM, PN_GROWS + 16, wave, lane, CC.h[l - 1][1]); }
                 }
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_W0 + l];
                 constexpr int xrow0 = (XYZ && (l == 0 || l == 3)) ? PN_EROWS(CQ) : PN_GROWS;
-                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, xrow0);
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, xrow0);
                 NSK_BAR();
                 if constexpr (l == 3) NSK_PH(14); NSK_PHI(14);
                 if constexpr (l == 3) {        // second input panel of layer 3: h2 (G panel unchanged)
                     const f4* h2 = XYZ ? C.h[2] : CC.h[2];
-                    if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS, wave, lane, h2[0]);
-                    if (!NSK_DBG(A, 14)) pn_put(pn, PN_GROWS + 16, wave, lane, h2[1]);
+                    if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS, wave, lane, h2[0]);
+                    if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16, wave, lane, h2[1]);
                     NSK_BAR();
                     constexpr TrainPhase P2 = plan.p[PL::P_W3H];
-                    if (!NSK_DBG(A, 13)) pn_tiles<P2.nslots>(pn, P2.RT, P2.NC, P2.rowsum, wave, lane, acc + P2.slot0);
+                    if (!NSK_DBG(A, 13)) pn_tiles<P2.nslots>(pn, PM, P2.RT, P2.NC, P2.rowsum, wave, lane, acc + P2.slot0);
                     NSK_BAR();
                 }
             }
@@ -440,12 +436,12 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 f4 pq;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
-                if (!NSK_DBG(A, 14)) pn_put(pn, 0, wave, lane, pq);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, pq);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PN_EROWS(CQ) + 16 * q, wave, lane, ge[q]);
+                for (int q = 0; q < 6; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_EROWS(CQ) + 16 * q, wave, lane, ge[q]);
                 NSK_BAR();
                 constexpr TrainPhase P = plan.p[PL::P_DB];
-                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PN_EROWS(CQ));
+                if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PN_EROWS(CQ));
                 NSK_BAR();
             }
             if constexpr (RAYS) {

@@ -12,7 +12,9 @@ ctx = pkg.Context(0); ctx.set_render_opts(); ctx.load_scene(sc["bound"], sc["gri
 cu = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
 ro, rd, gd, gc = cu(r["rays_o"]), cu(r["rays_d"]), cu(r["gt_depth"]), cu(r["gt_color"])
 loss = torch.zeros(1, device="cuda")
-for name, extra in [("base", 0), ("no_scatter", 1 << 9), ("no_barriers", 1 << 12), ("no_tiles", 1 << 13), ("no_tiles_put_bar", (1 << 12) | (1 << 13) | (1 << 14)), ("no_tiles_put_bar_scatter", (1 << 9) | (1 << 12) | (1 << 13) | (1 << 14))]:
+# NOT offered: dropping the phase barriers (bit 12).  The scatter's run table lives in the panel's head, so without barriers another wave's
+# panel writes turn into scatter addresses: the run faulted the GPU (round 2).  Every ablation here keeps the barriers.
+for name, extra in [("base", 0), ("no_scatter", 1 << 9), ("no_tiles", 1 << 13), ("no_tiles_put", (1 << 13) | (1 << 14)), ("no_tiles_put_scatter", (1 << 9) | (1 << 13) | (1 << 14))]:
     with torch.cuda.stream(ctx.tstream):
         for i in range(3):
             ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.5, True, flags=3 | extra, loss=loss); ctx.zero_grads()

@@ -355,7 +355,8 @@ def main():
                    "id": args.workload, "rays_per_gpu": N, "samples_per_ray": 48, "stage": args.stage,
                    "grid_shapes": {k: list(v.shape) for k, v in res["sc"]["grids"].items()},
                    "matmul": "fp32 operands as bf16 pieces on the matrix cores with fp32 accumulation (3 pieces = fp32-accurate: forward, frozen-decoder "
-                             "backward chains), fp32 MFMA for the trainable decoder's chain, its weight-gradient panels and the grid-gradient scatter",
+                             "backward chains; 2 pieces = 16 significant bits: the trainable decoder's weight-gradient panels), fp32 MFMA for the trainable "
+                             "decoder's chain and the grid-gradient scatter",
                    "frustum_feature_selection": res["mask_frac"] is not None, "marked_voxel_fraction": res["mask_frac"],
                    "parallelism": "rays sharded x%d, 1 all-reduce/step of %d floats (%.2f MB: marked voxels of the trained levels + colour decoder + loss; "
                                   "the dense gradient slab is %d floats)" % (world, res["exchange_floats"], 4e-6 * res["exchange_floats"], res["slab_floats"])},
@@ -363,11 +364,11 @@ def main():
     }
     if world == 1 and not args.no_extras:
         extras = {}
-        for name, wname, stage, n, k in (("K3_fine_stage", "K3", "fine", W["K3"]["rays"], 50), ("K2_color", "K2", "color", W["K2"]["rays"], 100),
-                                         ("K4_shard_color", "K4", "color", W["K4"]["rays"], 100)):
+        for name, wname, stage, n, k in (("K3_fine_stage", "K3", "fine", W["K3"]["rays"], 100), ("K2_color", "K2", "color", W["K2"]["rays"], 300),
+                                         ("K4_shard_color", "K4", "color", W["K4"]["rays"], 300)):
             if wname == args.workload and stage == args.stage and n == N:
                 continue
-            r = run_workload(W[wname], stage, n, k, 10, local, rank, world, None, frustum=not args.no_frustum_mask)
+            r = run_workload(W[wname], stage, n, k, 20, local, rank, world, None, frustum=not args.no_frustum_mask)
             s = summarize(r, stage, n, k, 1)
             extras[name] = {"workload": W[wname]["name"], "stage": stage, "rays": n, "steps": k, "value": s["value"], "unit": "rays/s",
                             "ms_per_step": s["ms_per_step"], "roofline_frac": s["roofline"]["frac"], "roofline_kernel": s["roofline"]["kernel"],

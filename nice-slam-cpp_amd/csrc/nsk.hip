@@ -1332,20 +1332,26 @@ static void split_wgs(int num_cu, int ntasks, int n, const int* cost, int* wg_en
 static void split_wgs_train(int num_cu, int ntasks, int n, const int* cost, int train_role, int* wg_end)
 {
     const int groups = std::max(1, (ntasks + 7) / 8);
-    long best = -1; int best_wt = 1;
     int fsum = 0;
     for (int r = 0; r < n; ++r) if (r != train_role) fsum += cost[r];
-    for (int wt = 1; wt <= num_cu - (n - 1); ++wt) {
-        long t = (long)((groups + wt - 1) / wt) * cost[train_role] * 1;      // one task per wave per iteration
+    // For every iteration count the role could run, give it the FEWEST workgroups that reach it: more would not shorten it (its time is
+    // a step function) and would starve the frozen roles (1250 rays: 3 iterations need 157 workgroups; the 190 a cost-proportional
+    // split hands it left the frozen roles as the kernel's tail, 120 us against 94 us).
+    long best = -1; int best_wt = 1;
+    const int wt_max = std::min(groups, num_cu - (n - 1));
+    for (int iters = (groups + wt_max - 1) / wt_max; iters <= groups; ++iters) {
+        const int wt = (groups + iters - 1) / iters;
+        if (wt > wt_max) continue;
+        long t = (long)iters * cost[train_role];
         const int rest = num_cu - wt;
         for (int r = 0; r < n; ++r) {
             if (r == train_role) continue;
             const int wr = std::max(1, (int)((long)rest * cost[r] / std::max(1, fsum)));
             t = std::max(t, (long)((ntasks + 8 * wr - 1) / (8 * wr)) * cost[r]);
         }
-        if (best < 0 || t < best || (t == best && wt <= groups)) { best = t; best_wt = wt; }   // ties: the most workgroups the role can use
+        if (best < 0 || t < best) { best = t; best_wt = wt; }
+        if ((long)iters * cost[train_role] > best) break;          // more iterations only get slower from here
     }
-    best_wt = std::min(best_wt, groups);
     const int rest = num_cu - best_wt;
     int used = 0;
     for (int r = 0; r < n; ++r) {

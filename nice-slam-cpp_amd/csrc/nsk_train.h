@@ -343,17 +343,23 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 if constexpr (XYZ) { C.h[l - 1][0] = src[0]; C.h[l - 1][1] = src[64]; }
                 else { CC.h[l - 1][0] = src[0]; CC.h[l - 1][1] = src[64]; }
             }
+            if constexpr (l == 2) NSK_PH(20);
             if constexpr (XYZ) {
                 gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);                 // g_c += fc[l]^T g_h
+                if constexpr (l == 2) NSK_PH(21);
                 // ---- phase FC_l: G = g_h, X = c ------------------------------------------------------------
                 if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, gh[0]);
                 if (!NSK_DBG(A, 14)) pn_put(pn, PM, 16, wave, lane, gh[1]);
 #pragma unroll
                 for (int q = 0; q < CQ; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16 * q, wave, lane, C.xc[q]);
+                if constexpr (l == 2) NSK_PH(22);
                 NSK_BAR();
+                if constexpr (l == 2) NSK_PH(23);
                 constexpr TrainPhase P = plan.p[PL::P_FC0 + l];
                 if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0);
+                if constexpr (l == 2) NSK_PH(24);
                 NSK_BAR();
+                if constexpr (l == 2) NSK_PH(25);
             }
             if constexpr (l == 3) NSK_PH(13); NSK_PHI(13);
             f4 ga[2];
@@ -375,11 +381,15 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                     if constexpr (l == 0 || l == 3) { pn_put(pn, PM, PN_GROWS, wave, lane, CC.xc[0]); pn_put(pn, PM, PN_GROWS + 16, wave, lane, CC.xc[1]); }
                     else { pn_put(pn, PM, PN_GROWS, wave, lane, CC.h[l - 1][0]); pn_put(pn, PM, PN_GROWS + 16, wave, lane, CC.h[l - 1][1]); }
                 }
+                if constexpr (l == 2) NSK_PH(26);
                 NSK_BAR();
+                if constexpr (l == 2) NSK_PH(27);
                 constexpr TrainPhase P = plan.p[PL::P_W0 + l];
                 constexpr int xrow0 = (XYZ && (l == 0 || l == 3)) ? PN_EROWS(CQ) : PN_GROWS;
                 if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, xrow0);
+                if constexpr (l == 2) NSK_PH(28);
                 NSK_BAR();
+                if constexpr (l == 2) NSK_PH(29);
                 if constexpr (l == 3) NSK_PH(14); NSK_PHI(14);
                 if constexpr (l == 3) {        // second input panel of layer 3: h2 (G panel unchanged)
                     const f4* h2 = XYZ ? C.h[2] : CC.h[2];
@@ -400,6 +410,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                     f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
                     gemm<2, 2>(bimg, MlpBwdImg::WT(l), lane, ga, ghn);
                     gh[0] = ghn[0]; gh[1] = ghn[1];
+                    if constexpr (l == 2) NSK_PH(30);
                 }
             } else {
                 if constexpr (l == 3) gemm<2, 2>(bimg, CoarseBwdImg::W3CT, lane, ga, gc);

@@ -36,3 +36,11 @@ for itn in (0, 1):
     tt = np.median(ph[:, :, 32 + 32 * itn: 64 + 32 * itn].reshape(-1, 32), axis=0)
     t0 = np.median(ph[:, :, 32].reshape(-1))
     print("iteration", itn, "start at", int(tt[0] - t0), " ".join("%d:%d" % (k, tt[k] - tt[0]) for k in order))
+
+# layer 2 in detail (last iteration), per wave of workgroup 0: 20 start, 21 after fc^T gemm, 22 after puts, 23 after barrier, 24 after FC tiles,
+# 25 after barrier, 26 after puts (W phase), 27 after barrier, 28 after W tiles, 29 after barrier, 30 after W^T gemm
+for w in range(8):
+    t = ph[0, w]
+    print("wg 0 wave", w, "layer 2:", " ".join("%d:%d" % (k, t[k] - t[20]) for k in range(20, 31)))
+tm = np.median(ph[:, :, 20:31].reshape(-1, 11), axis=0)
+print("median over 8 wgs x 8 waves:", " ".join("%d:%d" % (20 + k, tm[k] - tm[0]) for k in range(11)))

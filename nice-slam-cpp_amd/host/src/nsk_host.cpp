@@ -535,7 +535,7 @@ torch::Tensor Tracker::optimize_cam_in_batch(torch::Tensor cam_tensor, torch::Te
     torch::Tensor cam_cpu = cam_tensor.detach().to(torch::kCPU, torch::kFloat32).contiguous();
     D.cam.upload(cam_cpu.data_ptr<float>(), 7);
     const int N = batch_size;
-    D.rays.ensure((size_t)N); D.losses.ensure(4); D.m.ensure(16);
+    D.rays.ensure((size_t)N); D.losses.ensure(8); D.m.ensure(16);      // losses: [loss, d loss / d pose (7)]
     nskh::set_bound_ctx(bound);
     check(nsk_set_render_opts(ctx(), renderer.N_samples, renderer.N_surface, renderer.lindisp, renderer.perturb, renderer.occupancy, 0));
     nskh::sync_grids(c);
@@ -553,7 +553,6 @@ torch::Tensor Tracker::optimize_cam_in_batch(torch::Tensor cam_tensor, torch::Te
     check(nsk_rays_backward(ctx(), N, R.pi.p, R.pj.p, fx, fy, cx, cy, 0, R.g_ro.p, R.g_rd.p, g_c2w));
     check(nsk_camera_backward(ctx(), D.cam.p, g_c2w, D.losses.p + 1));          // losses[1..7] = d loss / d pose
     float h[8];
-    D.losses.ensure(8);
     D.losses.download(h, 8);
     cam_tensor.mutable_grad() = torch::from_blob(h + 1, {7}, torch::kFloat32).clone().to(cam_tensor.device());       // loss.backward() :84
     optimizer.step();                                                                                              // :85

@@ -336,13 +336,18 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         f4 ge[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
+        auto load_h = [&](auto KC) {
+            constexpr int k = decltype(KC)::value;
+            const f4* src = A.hsave + ((size_t)htask * 10 + 2 * k) * 64 + lane;
+            if constexpr (XYZ) { C.h[k][0] = src[0]; C.h[k][1] = src[64]; }
+            else { CC.h[k][0] = src[0]; CC.h[k][1] = src[64]; }
+        };
+        if constexpr (SAVED) load_h(std::integral_constant<int, 3>{});
         auto layer = [&](auto LC) {
             constexpr int l = decltype(LC)::value;
-            if constexpr (SAVED && l >= 1) {          // h[l-1] is the X operand of this layer's weight phase: fetch it one phase ahead
-                const f4* src = A.hsave + ((size_t)htask * 10 + 2 * (l - 1)) * 64 + lane;
-                if constexpr (XYZ) { C.h[l - 1][0] = src[0]; C.h[l - 1][1] = src[64]; }
-                else { CC.h[l - 1][0] = src[0]; CC.h[l - 1][1] = src[64]; }
-            }
+            // h[l-1] is the X operand of this layer's weight phase.  It is fetched a whole layer ahead (h[3] at the top of the iteration):
+            // one phase ahead, as it was, every W phase opened with s_waitcnt vmcnt on a load issued ~1000 cycles earlier
+            if constexpr (SAVED && l >= 2) load_h(std::integral_constant<int, l - 2>{});
             if constexpr (l == 2) NSK_PH(20);
             if constexpr (XYZ) {
                 gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);                 // g_c += fc[l]^T g_h

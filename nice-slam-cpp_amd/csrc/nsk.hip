@@ -1580,7 +1580,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         }
         MA.which[n] = w; MA.train[n] = train ? 1 : 0;
         // relative cost of one tile of a frozen role against one 8-tile iteration of the trainable role (= 1000)
-        const int frozen_cost = c->tune_frozen_cost > 0 ? c->tune_frozen_cost : 190;
+        const int frozen_cost = c->tune_frozen_cost > 0 ? c->tune_frozen_cost : 165;
         cost[n] = train ? 1000 : frozen_cost;
         lds = std::max(lds, bwd_lds_bytes(w, train));
         if (train) train_role = (train_role == -1 && w != 2) ? n : -2;     // -2: more than one trainable decoder, or the fine one (its

@@ -207,6 +207,22 @@ int nsk_rays_from_camera(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int3
 int nsk_pose_step(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy, float cx, float cy, int mode,
                   const float* d_g_rays_o, const float* d_g_rays_d, float* d_cam, float* d_m, float* d_v, float lr, float b1, float b2,
                   float eps, int step, float* d_g_cam_out);
+/* One launch for the whole ray preparation of an iteration (src/Mapper.cpp:376-427 for a window of frames, src/Tracker.cpp:44-58 for
+ * one): for each of `nframes` frames, rays_per_frame times  nsk_sample_pixels (window [H0,H1) x [W0,W1), frame's own seed) ->
+ * nsk_gather_pixels (frame's images, [H][W] / [H][W][3]) -> nsk_rays_from_pixels (pose = 12 floats c2w) or nsk_rays_from_camera
+ * (pose_is_cam7: 7 floats quaternion + translation) -> nsk_inside_filter, with the arithmetic of those entry points (results are
+ * bit-identical; tests/test_gpu_dist.py).  Outputs are [nframes * rays_per_frame] arrays, frame-major; d_keep may be NULL (no
+ * filter), d_color / d_gt_color may be NULL.  The frame table is read on the host at call time (at most 64 frames per call).
+ * The reference spends 3 kernels and ~15 small tensor ops per frame here; the device-resident Mapper iteration spent 16 launches. */
+typedef struct nsk_frame_rays {
+    const float* d_depth; const float* d_color;      /* the frame's images on the device */
+    const float* d_pose;                             /* device: 12 floats (c2w rows) or 7 floats (pose vector) */
+    int pose_is_cam7;
+    unsigned long long seed;                         /* pixel-draw seed of this frame in this iteration */
+} nsk_frame_rays;
+int nsk_prepare_rays(nsk_ctx* ctx, int nframes, const nsk_frame_rays* h_frames, int rays_per_frame, int H0, int H1, int W0, int W1,
+                     int H, int W, float fx, float fy, float cx, float cy, int mode, int32_t* d_pix_i, int32_t* d_pix_j,
+                     float* d_gt_depth, float* d_gt_color, float* d_rays_o, float* d_rays_d, uint8_t* d_keep);
 /* d loss / d c2w (12 floats, overwritten) from per-ray gradients */
 int nsk_rays_backward(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy,
                       float cx, float cy, int mode, const float* d_g_rays_o, const float* d_g_rays_d, float* d_g_c2w);

@@ -323,11 +323,19 @@ __global__ __launch_bounds__(256) void k_rays_backward(int n, const int* pi, con
 // quad2rotation / get_camera_from_tensor, reference include/torchlib/utils.h:174-210
 __device__ __forceinline__ void camera_matrix(const float* cam, float* c2w)
 {
-    float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
-    float two_s = 2.f / (qr * qr + qi * qi + qj * qj + qk * qk);
-    float R[9] = {1.f - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
-                  two_s * (qi * qj + qk * qr), 1.f - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qr),
-                  two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1.f - two_s * (qi * qi + qj * qj)};
+    // every product and sum rounded on its own, as the reference's tensor ops do.  The pragma matters: hipcc contracts a * b + c into an
+    // FMA across statements by default (and HIP's __fmul_rn / __fadd_rn are plain operators), so without it the matrix depended on the
+    // kernel this is inlined into -- k_rays_from_camera and k_prepare_rays differed in the last bit.
+#pragma clang fp contract(off)
+    const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
+    const float rr = qr * qr, ii = qi * qi, jj = qj * qj, kk = qk * qk;
+    const float ssum = ((rr + ii) + jj) + kk;
+    const float two_s = 2.f / ssum;
+    const float ij = qi * qj, ik = qi * qk, jk = qj * qk, ir = qi * qr, jr = qj * qr, kr = qk * qr;
+    const float s0 = jj + kk, s1 = ii + kk, s2 = ii + jj;
+    const float a01 = ij - kr, a02 = ik + jr, a10 = ij + kr, a12 = jk - ir, a20 = ik - jr, a21 = jk + ir;
+    const float t0 = two_s * s0, t1 = two_s * s1, t2 = two_s * s2;
+    float R[9] = {1.f - t0, two_s * a01, two_s * a02, two_s * a10, 1.f - t1, two_s * a12, two_s * a20, two_s * a21, 1.f - t2};
     for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) c2w[4 * a + b] = R[3 * a + b]; c2w[4 * a + 3] = cam[4 + a]; }
 }
 __global__ void k_camera_from_tensor(const float* cam, float* c2w) { camera_matrix(cam, c2w); }
@@ -410,6 +418,46 @@ __global__ void k_inside_filter(RParams R, int N, const float* ro, const float* 
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     keep[n] = ray_box_far(R.bound, ro[3 * n], ro[3 * n + 1], ro[3 * n + 2], rd[3 * n], rd[3 * n + 1], rd[3 * n + 2]) >= gt[n];
+}
+
+// the whole ray preparation of an iteration in one launch (nsk_prepare_rays): the bodies of k_sample_pixels, k_gather_pixels,
+// k_rays_from_pixels / k_rays_from_camera and k_inside_filter, one thread per ray, frames from a table in the kernel arguments
+struct PrepFrame { const float* depth; const float* color; const float* pose; int cam7; unsigned long long seed; };
+struct PrepArgs {
+    PrepFrame f[16];
+    int nframes, per, H0, W0, Ww, W, mode;
+    unsigned long long total;
+    float fx, fy, cx, cy;
+    int* pi; int* pj; float* gd; float* gc; float* ro; float* rd; uint8_t* keep;
+    RParams R;
+};
+__global__ __launch_bounds__(256) void k_prepare_rays(PrepArgs A)
+{
+    const int fi = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;      // one frame per block row: the table index is wave-uniform
+    if (r >= A.per) return;
+    const int t = fi * A.per + r;
+    const PrepFrame& F = A.f[fi];
+    const unsigned long long ind = ((unsigned long long)hash_u32(F.seed, (uint32_t)r, 0x51u) * A.total) >> 32;      // k_sample_pixels
+    const int pi = A.W0 + (int)(ind % (unsigned long long)A.Ww), pj = A.H0 + (int)(ind / (unsigned long long)A.Ww);
+    A.pi[t] = pi; A.pj[t] = pj;
+    const size_t p = (size_t)pj * A.W + pi;                                                                         // k_gather_pixels
+    const float gd = F.depth[p];
+    A.gd[t] = gd;
+    if (F.color && A.gc) { A.gc[3 * t] = F.color[3 * p]; A.gc[3 * t + 1] = F.color[3 * p + 1]; A.gc[3 * t + 2] = F.color[3 * p + 2]; }
+    float c2w[12];
+    if (F.cam7) camera_matrix(F.pose, c2w);                                                                          // k_rays_from_camera
+    else for (int k = 0; k < 12; ++k) c2w[k] = F.pose[k];                                                            // k_rays_from_pixels
+    const float i = (float)pi, j = (float)pj;
+    const float d0 = div_rn(sub_rn(i, A.cx), A.fx);
+    const float d1 = (A.mode & 1) ? div_rn(sub_rn(i, A.cy), A.fy) : -div_rn(sub_rn(j, A.cy), A.fy);
+    const float d2 = -1.f;
+    float o[3], d[3];
+    for (int a = 0; a < 3; ++a) {
+        d[a] = add_rn(add_rn(mul_rn(d0, c2w[4 * a]), mul_rn(d1, c2w[4 * a + 1])), mul_rn(d2, c2w[4 * a + 2]));
+        o[a] = c2w[4 * a + 3];
+        A.rd[3 * t + a] = d[a]; A.ro[3 * t + a] = o[a];
+    }
+    if (A.keep) A.keep[t] = ray_box_far(A.R.bound, o[0], o[1], o[2], d[0], d[1], d[2]) >= gd;                        // k_inside_filter
 }
 
 // in-bound override for eval_points (reference src/Renderer.cpp:26-36)
@@ -1909,6 +1957,36 @@ extern "C" int nsk_pose_step(nsk_ctx* c, int n, const int32_t* pi, const int32_t
     HIPCHK(hipGetLastError());
     return 0;
 }
+extern "C" int nsk_prepare_rays(nsk_ctx* c, int nframes, const nsk_frame_rays* fr, int per, int H0, int H1, int W0, int W1, int H, int W,
+                                float fx, float fy, float cx, float cy, int mode, int32_t* pi, int32_t* pj, float* gd, float* gc,
+                                float* ro, float* rd, uint8_t* keep)
+{
+    if (!c || !fr || !pi || !pj || !gd || !ro || !rd) return fail("nsk_prepare_rays: null argument");
+    if (nframes < 1 || nframes > 64 || per < 1) return fail("nsk_prepare_rays: nframes must be 1..64 and rays_per_frame >= 1");
+    if (H1 <= H0 || W1 <= W0 || H0 < 0 || W0 < 0 || H1 > H || W1 > W) return fail("nsk_prepare_rays: window [%d,%d) x [%d,%d) outside the %d x %d image", H0, H1, W0, W1, H, W);
+    HIPCHK(hipSetDevice(c->device));
+    intr(mode, fx, fy, cx, cy);
+    for (int f0 = 0; f0 < nframes; f0 += 16) {
+        PrepArgs A;
+        memset(&A, 0, sizeof(A));
+        A.nframes = std::min(16, nframes - f0);
+        for (int i = 0; i < A.nframes; ++i) {
+            const nsk_frame_rays& s = fr[f0 + i];
+            if (!s.d_depth || !s.d_pose) return fail("nsk_prepare_rays: frame %d has no depth image or pose", f0 + i);
+            A.f[i].depth = s.d_depth; A.f[i].color = s.d_color; A.f[i].pose = s.d_pose; A.f[i].cam7 = s.pose_is_cam7; A.f[i].seed = s.seed;
+        }
+        const size_t o = (size_t)f0 * per;
+        A.per = per; A.H0 = H0; A.W0 = W0; A.Ww = W1 - W0; A.W = W; A.mode = mode;
+        A.total = (unsigned long long)(H1 - H0) * (unsigned long long)(W1 - W0);
+        A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy;
+        A.pi = pi + o; A.pj = pj + o; A.gd = gd + o; A.gc = gc ? gc + 3 * o : nullptr; A.ro = ro + 3 * o; A.rd = rd + 3 * o; A.keep = keep ? keep + o : nullptr;
+        A.R = c->R;
+        k_prepare_rays<<<dim3((per + 255) / 256, A.nframes), 256, 0, c->stream>>>(A);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
 extern "C" int nsk_inside_filter(nsk_ctx* c, int N, const float* ro, const float* rd, const float* gt, uint8_t* keep)
 {
     if (!c || !ro || !rd || !gt || !keep || N < 1) return fail("nsk_inside_filter: bad argument");

@@ -30,8 +30,10 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_a
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------------------
-// exact-sequence scalar helpers: the sampling geometry feeds sin(25*x) and ReLU kinks, so it is evaluated
-// with the same rounding sequence as the reference's libtorch ops (separate mul / add, no FMA contraction)
+// scalar helpers that spell out the operation sequence of the reference's libtorch ops for the sampling geometry (it feeds sin(25*x) and
+// ReLU kinks).  They fix the ORDER of operations; they are not contraction barriers: HIP's __fmul_rn / __fadd_rn are plain operators and
+// hipcc may fuse a product into the following sum (as the CPU path's BLAS does inside p @ B).  Where bit-equality between two kernels is
+// required (camera_matrix, nsk.hip) the function carries #pragma clang fp contract(off).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }

@@ -541,10 +541,10 @@ torch::Tensor Tracker::optimize_cam_in_batch(torch::Tensor cam_tensor, torch::Te
     nskh::sync_grids(c);
     decoders.sync_to_device();
     RayBufs& R = D.rays;
-    check(nsk_sample_pixels(ctx(), rng_seed++, N, ignore_edge_h, H - ignore_edge_h, ignore_edge_w, W - ignore_edge_w, R.pi.p, R.pj.p));      // utils.h:19-36
-    check(nsk_gather_pixels(ctx(), N, R.pi.p, R.pj.p, D.frame.H, D.frame.W, D.frame.depth.p, D.frame.color.p, R.gd.p, R.gc.p));               // :38-43
-    check(nsk_rays_from_camera(ctx(), N, R.pi.p, R.pj.p, fx, fy, cx, cy, D.cam.p, 0, R.ro.p, R.rd.p, nullptr));                              // :44-52 + utils.h:198
-    check(nsk_inside_filter(ctx(), N, R.ro.p, R.rd.p, R.gd.p, R.keep.p));                                                                    // Tracker.cpp:48-58
+    // utils.h:19-52 + :198 + Tracker.cpp:48-58 in one launch: pixel draw, ground-truth gather, pose -> rays, inside filter
+    const nsk_frame_rays fr = {D.frame.depth.p, D.frame.color.p, D.cam.p, 1, rng_seed++};
+    check(nsk_prepare_rays(ctx(), 1, &fr, N, ignore_edge_h, H - ignore_edge_h, ignore_edge_w, W - ignore_edge_w, D.frame.H, D.frame.W, fx, fy, cx, cy, 0,
+                           R.pi.p, R.pj.p, R.gd.p, R.gc.p, R.ro.p, R.rd.p, R.keep.p));
     check(nsk_set_ray_mask(ctx(), R.keep.p));
     check(nsk_track_step(ctx(), NSK_COLOR, N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, use_color_in_tracking ? 1 : 0,
                          handle_dynamic ? 1 : 0, 1, NSK_GRAD_RAYS, D.losses.p, R.g_ro.p, R.g_rd.p));      // stage "color": :61 (D19)
@@ -578,10 +578,9 @@ void Tracker::run(NICE decoders, torch::Tensor gt_color_t, torch::Tensor gt_dept
     check(nsk_sync(ctx()));
     const double t0 = now_us();
     for (int i = 0; i < iters; ++i) {                                                 // :108-112, every operand resident on the device
-        check(nsk_sample_pixels(ctx(), rng_seed++, N, ignore_edge_h, H - ignore_edge_h, ignore_edge_w, W - ignore_edge_w, R.pi.p, R.pj.p));
-        check(nsk_gather_pixels(ctx(), N, R.pi.p, R.pj.p, D.frame.H, D.frame.W, D.frame.depth.p, D.frame.color.p, R.gd.p, R.gc.p));
-        check(nsk_rays_from_camera(ctx(), N, R.pi.p, R.pj.p, fx, fy, cx, cy, D.cam.p, 0, R.ro.p, R.rd.p, nullptr));
-        check(nsk_inside_filter(ctx(), N, R.ro.p, R.rd.p, R.gd.p, R.keep.p));
+        const nsk_frame_rays fr = {D.frame.depth.p, D.frame.color.p, D.cam.p, 1, rng_seed++};
+        check(nsk_prepare_rays(ctx(), 1, &fr, N, ignore_edge_h, H - ignore_edge_h, ignore_edge_w, W - ignore_edge_w, D.frame.H, D.frame.W, fx, fy, cx, cy, 0,
+                               R.pi.p, R.pj.p, R.gd.p, R.gc.p, R.ro.p, R.rd.p, R.keep.p));
         check(nsk_set_ray_mask(ctx(), R.keep.p));
         check(nsk_track_step(ctx(), NSK_COLOR, N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, use_color_in_tracking ? 1 : 0,
                              handle_dynamic ? 1 : 0, 1, NSK_GRAD_RAYS, D.losses.p + i, R.g_ro.p, R.g_rd.p));
@@ -766,6 +765,7 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     // poses of the window's frames: fixed ones as 3x4 rows, BA ones (every frame but the oldest, :305-329) as 7-vectors with Adam moments
     std::vector<float> h_pose((size_t)nf * 12), h_cam((size_t)nf * 8, 0.f);
     std::vector<int> is_ba((size_t)nf, 0);
+    std::vector<nsk_frame_rays> frame_tab;
     for (int i = 0; i < nf; ++i) {
         const int f = optimize_frame[i];
         torch::Tensor c2w = (f != -1 ? keyframe_vector[f].est_c2w : cur_c2w).detach().to(torch::kCPU, torch::kFloat32).contiguous();
@@ -800,16 +800,16 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
         lr[NSK_GROUP_CAMERA] = 0.f;
         const bool ba_now = any_ba && stage == "color";                                       // :366-368
         // rays of every window frame (:376-414): pixel draw, ground-truth gather and ray generation on the device
+        // (one launch for the window: it was 3 per frame + the filter = 16 launches of a 118 us iteration with five frames)
+        frame_tab.resize(nf);
         for (int i = 0; i < nf; ++i) {
             const int f = optimize_frame[i];
             const DevFrame& F = f >= 0 ? *D.kf[f] : D.cur;
-            const size_t o = (size_t)i * pixs_per_image;
-            check(nsk_sample_pixels(ctx(), rng_seed + 0x100000001b3ull * (uint64_t)(joint_iter * nf + i + 1), pixs_per_image, 0, H, 0, W, R.pi.p + o, R.pj.p + o));
-            check(nsk_gather_pixels(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, F.H, F.W, F.depth.p, F.color.p, R.gd.p + o, R.gc.p + 3 * o));
-            if (is_ba[i]) check(nsk_rays_from_camera(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, fx, fy, cx, cy, D.cams.p + 8 * i, 0, R.ro.p + 3 * o, R.rd.p + 3 * o, nullptr));
-            else check(nsk_rays_from_pixels(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, fx, fy, cx, cy, D.poses.p + 12 * i, 0, R.ro.p + 3 * o, R.rd.p + 3 * o));
+            frame_tab[i] = nsk_frame_rays{F.depth.p, F.color.p, is_ba[i] ? D.cams.p + 8 * i : D.poses.p + 12 * i, is_ba[i] ? 1 : 0,
+                                          rng_seed + 0x100000001b3ull * (uint64_t)(joint_iter * nf + i + 1)};
         }
-        check(nsk_inside_filter(ctx(), N, R.ro.p, R.rd.p, R.gd.p, R.keep.p));                // :416-427: rays that leave the bound before their depth
+        check(nsk_prepare_rays(ctx(), nf, frame_tab.data(), pixs_per_image, 0, H, 0, W, D.cur.H, D.cur.W, fx, fy, cx, cy, 0, R.pi.p, R.pj.p, R.gd.p, R.gc.p,
+                               R.ro.p, R.rd.p, R.keep.p));                                    // :416-427 included: rays that leave the bound before their depth
         check(nsk_set_ray_mask(ctx(), R.keep.p));                                             // ... are neutralised in place (no count on the host)
         unsigned flags = NSK_GRAD_GRIDS | NSK_GRAD_DECODERS | (ba_now ? NSK_GRAD_RAYS : 0u);
         // src/Mapper.cpp:430 renders the literal "color" whatever the stage (D19); the colour term of the loss follows `stage` (:438)

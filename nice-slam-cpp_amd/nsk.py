@@ -22,7 +22,7 @@ SYMBOLS = (
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
     "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
-    "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_grad_slab", "nsk_grad_pack", "nsk_grad_unpack", "nsk_allreduce_grads", "nsk_last_call_stats",
+    "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_prepare_rays", "nsk_grad_slab", "nsk_grad_pack", "nsk_grad_unpack", "nsk_allreduce_grads", "nsk_last_call_stats",
     "nsk_profile_begin", "nsk_profile_end",
 )
 
@@ -206,6 +206,38 @@ class Context:
         pj = torch.empty_like(pi)
         _chk(lib().nsk_sample_pixels(self.h, C.c_ulonglong(seed), n, H0, H1, W0, W1, _ptr(pi), _ptr(pj)))
         return pi, pj
+
+    @_ordered
+    def prepare_rays(self, frames, rays_per_frame, window, intr, mode=0, want_keep=True):
+        """nsk_prepare_rays: pixel draw + ground-truth gather + ray generation + inside filter for a list of frames in one launch.
+        frames: list of dicts {depth [H,W] cuda, color [H,W,3] cuda or None, pose cuda (12 floats c2w or 7 floats), seed};
+        window = (H0, H1, W0, W1); returns dict of cuda tensors (pix_i, pix_j, gt_depth, gt_color, rays_o, rays_d, keep)"""
+        import torch
+
+        class FrameRays(C.Structure):
+            _fields_ = [("d_depth", C.c_void_p), ("d_color", C.c_void_p), ("d_pose", C.c_void_p), ("pose_is_cam7", C.c_int), ("seed", C.c_ulonglong)]
+        nf = len(frames)
+        tab = (FrameRays * nf)()
+        H, W = frames[0]["depth"].shape
+        for k, f in enumerate(frames):
+            tab[k].d_depth = f["depth"].data_ptr()
+            tab[k].d_color = f["color"].data_ptr() if f.get("color") is not None else None
+            tab[k].d_pose = f["pose"].data_ptr()
+            tab[k].pose_is_cam7 = 1 if f["pose"].numel() == 7 else 0
+            tab[k].seed = int(f["seed"])
+        n = nf * rays_per_frame
+        dev = frames[0]["depth"].device
+        out = dict(pix_i=torch.empty(n, dtype=torch.int32, device=dev), pix_j=torch.empty(n, dtype=torch.int32, device=dev),
+                   gt_depth=torch.empty(n, dtype=torch.float32, device=dev), gt_color=torch.empty((n, 3), dtype=torch.float32, device=dev),
+                   rays_o=torch.empty((n, 3), dtype=torch.float32, device=dev), rays_d=torch.empty((n, 3), dtype=torch.float32, device=dev),
+                   keep=torch.empty(n, dtype=torch.uint8, device=dev) if want_keep else None)
+        has_color = all(f.get("color") is not None for f in frames)
+        H0, H1, W0, W1 = window
+        fx, fy, cx, cy = intr
+        _chk(lib().nsk_prepare_rays(self.h, nf, tab, rays_per_frame, H0, H1, W0, W1, H, W, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), mode,
+                                    _ptr(out["pix_i"]), _ptr(out["pix_j"]), _ptr(out["gt_depth"]), _ptr(out["gt_color"]) if has_color else None,
+                                    _ptr(out["rays_o"]), _ptr(out["rays_d"]), _ptr(out["keep"]) if want_keep else None))
+        return out
 
     @_ordered
     def gather_pixels(self, pix_i, pix_j, depth_img, color_img=None):

@@ -531,3 +531,44 @@ def test_fused_pose_kernels_equal_their_parts():
         ctx.pose_step(pi, pj, intr, g_ro, g_rd, cam_b, m_b, v_b, 1e-2, step, g_cam_out=g_out)
         assert torch.equal(g_out, g_cam)
         assert torch.equal(cam_a, cam_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b)
+
+
+def test_prepare_rays_equals_the_separate_entry_points():
+    """nsk_prepare_rays (one launch for a window of frames) against nsk_sample_pixels + nsk_gather_pixels + nsk_rays_from_pixels /
+    nsk_rays_from_camera + nsk_inside_filter frame by frame: every output bit for bit (two frames, one posed by a 7-vector, one by a
+    c2w matrix; 300 rays each, a cropped window as the Tracker uses)"""
+    import torch
+    sc = scenes.make_scene(3, scenes.SMALL_GRID_SHAPES)
+    ctx = make_ctx(sc)
+    rng = np.random.default_rng(5)
+    H, W = 96, 128
+    intr = (110.0, 108.0, 63.5, 47.5)
+    frames = []
+    for k in range(2):
+        depth = torch.tensor(rng.uniform(0.5, 6.0, (H, W)).astype(np.float32), device="cuda")
+        color = torch.tensor(rng.random((H, W, 3)).astype(np.float32), device="cuda")
+        if k == 0:
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            pose = torch.tensor(np.concatenate([q, rng.uniform(-1, 1, 3)]).astype(np.float32), device="cuda")
+        else:
+            c2w = np.asarray(scenes.make_camera(np.random.default_rng(7), sc["bound"], "y"), np.float32).reshape(-1)[:12]
+            pose = torch.tensor(np.ascontiguousarray(c2w), device="cuda")
+        frames.append(dict(depth=depth, color=color, pose=pose, seed=1000 + 17 * k))
+    n = 300
+    win = (8, H - 8, 12, W - 12)
+    got = ctx.prepare_rays(frames, n, win, intr)
+    ctx.sync()
+    for k, f in enumerate(frames):
+        pi, pj = ctx.sample_pixels(f["seed"], n, *win)
+        gd, gc = ctx.gather_pixels(pi, pj, f["depth"], f["color"])
+        if f["pose"].numel() == 7:
+            ro, rd = ctx.rays_from_camera(pi, pj, intr, f["pose"])
+        else:
+            ro, rd = ctx.rays_from_pixels(pi, pj, intr, f["pose"])
+        keep = ctx.inside_filter(ro, rd, gd)
+        ctx.sync()
+        sl = slice(k * n, (k + 1) * n)
+        for name, a, b in (("pix_i", got["pix_i"][sl], pi), ("pix_j", got["pix_j"][sl], pj), ("gt_depth", got["gt_depth"][sl], gd), ("gt_color", got["gt_color"][sl], gc),
+                           ("rays_o", got["rays_o"][sl], ro), ("rays_d", got["rays_d"][sl], rd), ("keep", got["keep"][sl].bool(), keep)):
+            assert torch.equal(a.cpu().reshape(-1), b.cpu().reshape(-1)), (k, name)
+    ctx.close()

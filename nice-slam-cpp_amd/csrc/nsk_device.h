@@ -92,7 +92,7 @@ __device__ __forceinline__ float wave_max(float v)
 __global__ void k_depth_max(int N, const float* __restrict__ gt, const uint8_t* __restrict__ keep, float* __restrict__ out)
 {
     __shared__ float sh[16];
-    float m = -NSK_INF;
+    float m = keep ? 0.f : -NSK_INF;          // with a ray mask an empty selection is possible: its maximum is 0 (depths are >= 0), not -inf
     for (int i = threadIdx.x; i < N; i += blockDim.x) if (!keep || keep[i]) m = fmaxf(m, gt[i]);
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int 
     const float gt = has_gt ? gt_depth[nc] : 0.f;
     float gmax = gtmax_dev ? *gtmax_dev : gtmax_host;
     if (has_gt && !gtmax_dev && gtmax_host < 0.f) {         // batch maximum computed by every wave itself (small batches: one launch fewer)
-        float mx = -NSK_INF;
+        float mx = keep ? 0.f : -NSK_INF;                   // (see k_depth_max)
         for (int i = lane; i < N; i += 64) if (!keep || keep[i]) mx = fmaxf(mx, gt_depth[i]);
         gmax = wave_max(mx);
     }
@@ -911,7 +911,12 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
     float gD = 0.f, gV = 0.f, gC[3] = {0.f, 0.f, 0.f};
     const bool kept = !A.keep || A.keep[n];
     if (!kept) {
+        // a masked ray contributes exactly nothing, whatever its rendering came out as (a frame that looks out of the bound renders
+        // inf / NaN, and 0 * NaN would otherwise reach the grids: tests/test_gpu_configs.py::test_fully_masked_batch_is_a_no_op)
         if (A.loss && lane == 0) A.loss[n] = 0.f;
+        if (act) *reinterpret_cast<f4*>(A.g_raw + m * 4) = (f4)(0.f);
+        if (A.g_rays_d && lane < 3) { A.g_rays_d[3 * n + lane] = 0.f; A.g_rays_o[3 * n + lane] = 0.f; }
+        return;
     } else if (A.mode == 1) {
         gD = A.g_depth ? A.g_depth[n] : 0.f;
         gV = A.g_var ? A.g_var[n] : 0.f;

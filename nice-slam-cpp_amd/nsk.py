@@ -426,12 +426,15 @@ class Context:
         _chk(lib().nsk_camera_backward(self.h, _ptr(cam), _ptr(g_c2w), _ptr(g)))
         return g
 
-    @_ordered
     def inside_filter(self, rays_o, rays_d, gt_depth):
+        return self._inside_filter_u8(rays_o, rays_d, gt_depth).bool()       # (the conversion is a torch op: after the streams were ordered)
+
+    @_ordered
+    def _inside_filter_u8(self, rays_o, rays_d, gt_depth):
         import torch
         keep = torch.empty(rays_o.shape[0], dtype=torch.uint8, device=rays_o.device)
         _chk(lib().nsk_inside_filter(self.h, rays_o.shape[0], _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), _ptr(keep)))
-        return keep.bool()
+        return keep
 
     @_ordered
     def adam_vector(self, p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8):

@@ -429,3 +429,52 @@ def test_raw2outputs_standalone(occupancy, oracle32):
     T = np.cumprod(np.concatenate([np.ones((3, 1)), 1 - alpha + 1e-10], 1), 1)[:, :-1]
     wref = alpha * T
     assert rel_l2(w.cpu().numpy(), wref) < 1e-5 and rel_l2(depth.cpu().numpy(), (wref * z16).sum(1)) < 1e-5
+
+
+@pytest.mark.parametrize("n_rays,sort_mode", [(1, -1), (17, 1), (45, -1), (333, 1)])
+def test_mapping_step_on_ragged_batches(n_rays, sort_mode, oracle32, oracle64):
+    """ragged inputs through the whole mapping step: one ray; ray counts that leave the last 16-sample tile, the last 8-tile panel
+    iteration and the last 16-ray sampling workgroup partly empty; in ray order and in cell-sorted order (45 rays = 2160 samples is
+    just past the automatic sort threshold).  Loss and every gradient against the oracle, all rays."""
+    sc = scenes.make_scene(31, scenes.SMALL_GRID_SHAPES, grid_std=0.05, bias_std=0.1)
+    rays = scenes.make_rays(32, n_rays, sc["bound"], n_frames=1, zero_frac=0.0)
+    ctx = make_ctx(sc, trainable=["color"])
+    ctx.set_sort_mode(sort_mode)
+    loss_t = torch.zeros(1, device="cuda")
+    gmax = float(rays["gt_depth"].max())
+    ctx.map_step("color", cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"]), cu(rays["gt_color"]), gmax, 0.5, True, flags=3, loss=loss_t)
+    l_ref, bw = _oracle_grads(oracle32, sc, sc["grids"], sc["decoders"], rays, "color", 0.5, gmax)
+    bw64 = _oracle_grads(oracle64, sc, sc["grids"], sc["decoders"], rays, "color", 0.5, gmax)[1]
+    assert abs(float(loss_t) - l_ref) < 2e-5 * abs(l_ref)
+    pairs = [("grid_" + k, ctx.grid_download(k, grad=True), bw["g_grids"][k], bw64["g_grids"][k]) for k in ("middle", "fine", "color")]
+    pairs.append(("colour decoder", ctx.decoder_download("color", grad=True), bw["g_decoders"]["color"], bw64["g_decoders"]["color"]))
+    for name, got, ref, ref64 in pairs:
+        e, e64, eo = rel_l2(got, ref), rel_l2(got, ref64), rel_l2(ref, ref64)
+        assert e < TOL or e64 < 5 * eo + TOL, "%d rays, sort %d: d loss / d %s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (n_rays, sort_mode, name, e, e64, eo)
+    ctx.close()
+
+
+def test_fully_masked_batch_is_a_no_op(oracle32):
+    """every ray switched off by the ray mask (what the inside filter returns for a frame that looks out of the bound): zero loss, zero
+    gradients everywhere, and an Adam step that leaves grids and decoder bit-identical"""
+    sc = scenes.make_scene(33, scenes.SMALL_GRID_SHAPES, grid_std=0.05, bias_std=0.1)
+    rays = scenes.make_rays(34, 64, sc["bound"], n_frames=1)
+    ctx = make_ctx(sc, trainable=["color"])
+    before = {k: ctx.grid_download(k) for k in ("middle", "fine", "color")}
+    dec_before = ctx.decoder_download("color")
+    keep = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    loss_t = torch.ones(1, device="cuda")
+    ctx.set_ray_mask(keep)
+    ctx.map_step("color", cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"]), cu(rays["gt_color"]), -1.0, 0.5, True, flags=3, loss=loss_t)
+    ctx.set_ray_mask(None)
+    assert float(loss_t) == 0.0
+    for k in ("middle", "fine", "color"):
+        g = ctx.grid_download(k, grad=True)
+        assert np.isfinite(g).all() and not g.any(), k
+    gd = ctx.decoder_download("color", grad=True)
+    assert np.isfinite(gd).all() and not gd.any()
+    ctx.adam_step(LR["color"])
+    for k in ("middle", "fine", "color"):
+        assert np.array_equal(ctx.grid_download(k), before[k]), k
+    assert np.array_equal(ctx.decoder_download("color"), dec_before)
+    ctx.close()

@@ -478,3 +478,32 @@ def test_fully_masked_batch_is_a_no_op(oracle32):
         assert np.array_equal(ctx.grid_download(k), before[k]), k
     assert np.array_equal(ctx.decoder_download("color"), dec_before)
     ctx.close()
+
+
+def test_large_batch_gradient_is_the_sum_of_its_shards():
+    """size-independent property at a size no oracle run fits in the suite: 40 000 rays x 48 samples (1.92 M samples, 4x the largest
+    BASELINE config) in ONE mapping step against the same rays as four 10 000-ray steps that accumulate into the gradient slab (all
+    with the batch's global depth maximum, as ranks of a sharded run would): loss and every gradient agree to summation order"""
+    sc = scenes.make_scene(41, grid_std=0.05)
+    rays = scenes.make_rays(42, 40000, sc["bound"], n_frames=8)
+    gmax = float(rays["gt_depth"].max())
+    t = {k: cu(rays[k]) for k in ("rays_o", "rays_d", "gt_depth", "gt_color")}
+    out = []
+    for shards in (1, 4):
+        ctx = make_ctx(sc, trainable=["color"])
+        total = 0.0
+        loss_t = torch.zeros(1, device="cuda")
+        n = 40000 // shards
+        for k in range(shards):
+            sl = slice(k * n, (k + 1) * n)
+            ctx.map_step("color", t["rays_o"][sl], t["rays_d"][sl], t["gt_depth"][sl], t["gt_color"][sl], gmax, 0.5, True, flags=3, loss=loss_t)
+            total += float(loss_t)
+        g = {k: ctx.grid_download(k, grad=True) for k in ("middle", "fine", "color")}
+        g["dec"] = ctx.decoder_download("color", grad=True)
+        out.append((total, g))
+        ctx.close()
+    (l1, g1), (l4, g4) = out
+    assert np.isfinite(l1) and abs(l1 - l4) < 1e-5 * abs(l1)
+    for k in g1:
+        assert np.isfinite(g1[k]).all()
+        assert rel_l2(g1[k], g4[k]) < 1e-5, k

@@ -572,3 +572,33 @@ def test_prepare_rays_equals_the_separate_entry_points():
                            ("rays_o", got["rays_o"][sl], ro), ("rays_d", got["rays_d"][sl], rd), ("keep", got["keep"][sl].bool(), keep)):
             assert torch.equal(a.cpu().reshape(-1), b.cpu().reshape(-1)), (k, name)
     ctx.close()
+
+
+@pytest.mark.parametrize("n_samples,n_surface", [(24, 16), (20, 0), (32, 5)])
+def test_sample_counts_that_are_not_multiples_of_the_tile(n_samples, n_surface, oracle32, oracle64):
+    """S = 40, 20, 37 samples per ray: 16-sample tiles straddle rays (the per-tile ray-gradient sum falls back to per-sample adds, the
+    last tile of the batch is partly empty).  Forward outputs and the full backward (grids, trainable decoders, rays) against the oracle."""
+    sc = _scene(51)
+    rays = scenes.make_rays(52, 77, sc["bound"], n_frames=2, zero_frac=0.1)
+    gd = rays["gt_depth"]
+    N = rays["rays_o"].shape[0]                 # 76: two frames of 38
+    rng = np.random.default_rng(53)
+    g_rgb, g_d = rng.standard_normal((N, 3)).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    kw = dict(n_samples=n_samples, n_surface=n_surface)
+    frag = oracle64.ray_fragility(oracle64.opts(sc["bound"], **kw), sc["grids"], sc["decoders"], "color", rays["rays_o"], rays["rays_d"], gd)
+    keep = frag > 2e-5
+    assert keep.mean() > 0.5
+    g_rgb[~keep] = 0; g_d[~keep] = 0
+    ctx = make_ctx(sc, trainable=["color"], **kw)
+    rgb, depth, var, w = ctx.render_forward("color", cu(rays["rays_o"]), cu(rays["rays_d"]), cu(gd))
+    fw = oracle32.render_forward(oracle32.opts(sc["bound"], **kw), sc["grids"], sc["decoders"], "color", rays["rays_o"], rays["rays_d"], gd)
+    assert w.shape == (N, n_samples + n_surface)
+    assert rel_l2(depth.cpu().numpy(), fw["depth"]) < TOL and rel_l2(rgb.cpu().numpy(), fw["rgb"]) < TOL and rel_l2(w.cpu().numpy(), fw["weights"]) < TOL
+    ref = oracle32.render_backward(oracle32.opts(sc["bound"], **kw), sc["grids"], sc["decoders"], "color", rays["rays_o"], rays["rays_d"], gd, -1.0, g_rgb, g_d, None)
+    g_ro, g_rd = ctx.render_backward("color", cu(rays["rays_o"]), cu(rays["rays_d"]), cu(gd), -1.0, cu(g_rgb), cu(g_d), None, flags=7)
+    ctx.sync()
+    for k in ("middle", "fine", "color"):
+        assert rel_l2(ctx.grid_download(k, grad=True), ref["g_grids"][k]) < TOL, k
+    assert rel_l2(ctx.decoder_download("color", grad=True), ref["g_decoders"]["color"]) < TOL
+    assert rel_l2(g_ro.cpu().numpy(), ref["g_rays_o"]) < TOL and rel_l2(g_rd.cpu().numpy(), ref["g_rays_d"]) < TOL
+    ctx.close()

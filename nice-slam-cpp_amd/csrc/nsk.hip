@@ -688,6 +688,7 @@ struct nsk_ctx {
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     bool deterministic = false;             // debug: bit-reproducible gradients (see nsk_set_tuning in include/nsk.h)
     bool roctx = false;                     // roctx ranges around every profiled launch group (libroctx64, loaded on demand)
+    int tune_fwd_fine_cost = 0, tune_fwd_color_cost = 0;     // experiments: forward role costs (nsk_set_tuning "fwd_fine_cost" / "fwd_color_cost")
     int tune_skew = 0;                      // start offset of the upper four waves of a decoder workgroup, x 1024 cycles (wave_skew, nsk_device.h)
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
@@ -851,6 +852,8 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
 {
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
+    if (!strcmp(key, "fwd_fine_cost")) { c->tune_fwd_fine_cost = value; return 0; }
+    if (!strcmp(key, "fwd_color_cost")) { c->tune_fwd_color_cost = value; return 0; }
     if (!strcmp(key, "skew")) { if (value < 0 || value > 299) return fail("nsk_set_tuning: skew out of range"); c->tune_skew = value; return 0; }
     if (!strcmp(key, "deterministic")) { c->deterministic = value != 0; return 0; }
     if (!strcmp(key, "roctx")) { c->roctx = value != 0; return 0; }
@@ -1385,6 +1388,42 @@ static void split_wgs(int num_cu, int ntasks, int n, const int* cost, int* wg_en
     }
 }
 
+// Cost-proportional shares, then single workgroups moved from the role that would suffer least to the role that finishes last while
+// the modelled makespan (whole tiles per wave x cost) falls: a role's time is a step function of its workgroups, and the
+// proportional split alone left the forward 3-5 % behind the best split whenever a role sat just past a step (K3, K4 shard).
+static void split_wgs_balanced(int num_cu, int ntasks, int n, const int* cost, int* wg_end, int waves = 8)
+{
+    split_wgs(num_cu, ntasks, n, cost, wg_end, waves);
+    int w[4];
+    for (int r = 0; r < n; ++r) w[r] = wg_end[r] - (r ? wg_end[r - 1] : 0);
+    int used = wg_end[n - 1];
+    const int cap = std::max(1, (ntasks + waves - 1) / waves);
+    auto t_of = [&](int r, int wr) { return (long)((ntasks + waves * wr - 1) / (waves * wr)) * cost[r]; };
+    for (int r = 0; used < num_cu && r < 8 * n; ++r) {      // hand out what the rounding left, to whoever finishes last
+        int worst = 0;
+        for (int q = 1; q < n; ++q) if (t_of(q, w[q]) > t_of(worst, w[worst])) worst = q;
+        if (w[worst] >= cap) break;
+        ++w[worst]; ++used;
+    }
+    for (int it = 0; it < 64; ++it) {
+        int worst = 0;
+        for (int q = 1; q < n; ++q) if (t_of(q, w[q]) > t_of(worst, w[worst])) worst = q;
+        const long cur = t_of(worst, w[worst]);
+        if (w[worst] >= cap) break;
+        int donor = -1; long best = cur;
+        for (int q = 0; q < n; ++q) {
+            if (q == worst || w[q] <= 1) continue;
+            long m = std::max(t_of(q, w[q] - 1), t_of(worst, w[worst] + 1));
+            for (int o = 0; o < n; ++o) if (o != q && o != worst) m = std::max(m, t_of(o, w[o]));
+            if (m < best) { best = m; donor = q; }
+        }
+        if (donor < 0) break;
+        --w[donor]; ++w[worst];
+    }
+    int acc = 0;
+    for (int r = 0; r < n; ++r) { acc += w[r]; wg_end[r] = acc; }
+}
+
 // Backward with one trainable role: that role advances in whole iterations (8 tasks per workgroup, all its workgroups in
 // lockstep), so its time is ceil(groups / workgroups) iterations -- a step function -- while a frozen role's time falls
 // smoothly with its workgroups.  Pick the trainable role's share by minimising the modelled makespan instead of in
@@ -1428,7 +1467,7 @@ static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const fl
     int n = 0;
     for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) ++n;
     if (n == 1) return launch_decode_fwd(c, STAGE_DEC[stage][0], M, S, ro, rd, nullptr, save_masks);
-    static const int fcost[4] = {96, 240, 320, 240};
+    static const int fcost[4] = {96, 240, 292, 248};      // issue cycles per tile of the roles (coarse fp32; middle 7 560, fine 9 380, colour 7 710 + its block-output stores)
     MultiArgs MA;
     memset(&MA, 0, sizeof(MA));
     int cost[3]; size_t lds = 0;
@@ -1438,11 +1477,11 @@ static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const fl
         MA.a[r].masks = save_masks ? c->ws.masks[w] : nullptr;
         if (save_masks) c->ws.hsave_M[w] = 0;
         if (saves_h(c, w, save_masks)) { CHK(ensure_hsave(c, w, M)); MA.a[r].hsave = c->ws.hsave[w]; c->ws.hsave_M[w] = M; }
-        MA.which[r] = w; cost[r] = fcost[w];
+        MA.which[r] = w; cost[r] = (w == 2 && c->tune_fwd_fine_cost > 0) ? c->tune_fwd_fine_cost : ((w == 3 && c->tune_fwd_color_cost > 0) ? c->tune_fwd_color_cost : fcost[w]);
         lds = std::max(lds, fwd_img_floats(w) * 4);
     }
     MA.n = n;
-    split_wgs(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end, 8);
+    split_wgs_balanced(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end, 8);
     ProfScope ps(c, "decode_fwd_multi");
     if (c->matmul_mode == 1) {
         size_t lds16 = 0;
@@ -1647,7 +1686,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
     }
     MA.n = n;
     if (train_role >= 0 && n > 1) split_wgs_train(c->num_cu, (M + 15) / 16, n, cost, train_role, MA.wg_end);
-    else split_wgs(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end);
+    else split_wgs_balanced(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end);
     const int extra = d_loss ? 1 : 0;          // one more workgroup sums the per-ray losses written by k_composite
     if (d_loss) { MA.sum_src = c->ws.ray_loss; MA.sum_dst = d_loss; MA.sum_n = N; }
     {

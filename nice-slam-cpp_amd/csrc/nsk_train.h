@@ -275,6 +275,9 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     };
     int mm_next = 0;
     if (iters > 0) { stage_a(0, slot_sample(A, slot_of(0)), nx); stage_b(nx); mm_next = slot_sample(A, slot_of(1)); }
+    // (the same opaque use as before the scatter below: with the staged data complete on BOTH paths into the loop header the compiler
+    // places no vmcnt wait at the top of the iteration -- a wait there also waits for the previous iteration's atomics)
+    if constexpr (SAVED) asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
         NSK_PH(0); NSK_PHI(0);
@@ -377,7 +380,12 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, ga[0]);
                 if (!NSK_DBG(A, 14)) pn_put(pn, PM, 16, wave, lane, ga[1]);
                 if constexpr (XYZ) {
-                    if constexpr (l == 0 || l == 3) {
+                    if constexpr (l == 0) {
+                    } else if constexpr (l == 3) {
+                        // layer 3 has two inputs, e (its own panel rows) and h2: h2 goes into the X rows in the same phase -- the G panel
+                        // is the same for both products (this used to be a phase of its own: two more barriers per iteration)
+                        if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS, wave, lane, C.h[2][0]);
+                        if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16, wave, lane, C.h[2][1]);
                     } else {
                         if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS, wave, lane, C.h[l - 1][0]);
                         if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16, wave, lane, C.h[l - 1][1]);
@@ -392,12 +400,16 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 constexpr TrainPhase P = plan.p[PL::P_W0 + l];
                 constexpr int xrow0 = (XYZ && (l == 0 || l == 3)) ? PN_EROWS(CQ) : PN_GROWS;
                 if (!NSK_DBG(A, 13)) pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, xrow0);
+                if constexpr (XYZ && l == 3) {        // second input of layer 3 (h2, in the X rows), same phase; its four tiles go to waves 4..7
+                    constexpr TrainPhase P2 = plan.p[PL::P_W3H];      // (the e tiles above give waves 0..5 two tiles and waves 6, 7 one)
+                    if (!NSK_DBG(A, 13)) pn_tiles<P2.nslots>(pn, PM, P2.RT, P2.NC, P2.rowsum, (wave + 4) & 7, lane, acc + P2.slot0);
+                }
                 if constexpr (l == 2) NSK_PH(28);
                 NSK_BAR();
                 if constexpr (l == 2) NSK_PH(29);
                 if constexpr (l == 3) NSK_PH(14); NSK_PHI(14);
-                if constexpr (l == 3) {        // second input panel of layer 3: h2 (G panel unchanged)
-                    const f4* h2 = XYZ ? C.h[2] : CC.h[2];
+                if constexpr (!XYZ && l == 3) {        // coarse decoder: second input panel of layer 3: h2 (G panel unchanged)
+                    const f4* h2 = CC.h[2];
                     if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS, wave, lane, h2[0]);
                     if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16, wave, lane, h2[1]);
                     NSK_BAR();
@@ -502,6 +514,11 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         if (it + 1 < iters) {
             stage_b(nx);
         }
+        // Every staged load must have landed before the first atomic below: vmcnt retires in order, so a wait for any of them at the top of
+        // the next iteration (gr, the ReLU bits, h4 are first used there) is also a wait for this scatter's sixteen atomics, which take
+        // ~7 000 cycles to retire.  The use is unconditional on purpose: the waitcnt pass is path-insensitive, and under the `if` above
+        // it still saw a path (loads issued, use skipped) that reaches the loop header with the loads pending.
+        if constexpr (SAVED) asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
         NSK_PH(17); NSK_PHI(17);
         if (scat) {
             if (A.flags & 0x8000u) {        // deterministic debug mode: see decode_bwd_body
@@ -516,7 +533,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     pn_flush<plan.p[PL::P_OUT].nslots>(slab, plan.p[PL::P_OUT], wave, lane, acc + plan.p[PL::P_OUT].slot0);
 #define NSK_FLUSH(ID) if constexpr (plan.p[ID].nslots > 0) pn_flush<plan.p[ID].nslots>(slab, plan.p[ID], wave, lane, acc + plan.p[ID].slot0);
     NSK_FLUSH(1) NSK_FLUSH(2) NSK_FLUSH(3) NSK_FLUSH(4) NSK_FLUSH(5) NSK_FLUSH(6) NSK_FLUSH(7) NSK_FLUSH(8) NSK_FLUSH(9)
-    NSK_FLUSH(10) NSK_FLUSH(11) NSK_FLUSH(12)
+    NSK_FLUSH(10) NSK_FLUSH(12)
+    // (P_W3H = 11: for the MLP decoders its tiles were dealt to waves (tile + 4) & 7 -- see layer 3)
+    if constexpr (plan.p[PL::P_W3H].nslots > 0)
+        pn_flush<plan.p[PL::P_W3H].nslots>(slab, plan.p[PL::P_W3H], XYZ ? (wave + 4) & 7 : wave, lane, acc + plan.p[PL::P_W3H].slot0);
 #undef NSK_FLUSH
     NSK_PH(12);
 }

@@ -515,9 +515,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             stage_b(nx);
         }
         // Every staged load must have landed before the first atomic below: vmcnt retires in order, so a wait for any of them at the top of
-        // the next iteration (gr, the ReLU bits, h4 are first used there) is also a wait for this scatter's sixteen atomics, which take
-        // ~7 000 cycles to retire.  The use is unconditional on purpose: the waitcnt pass is path-insensitive, and under the `if` above
-        // it still saw a path (loads issued, use skipped) that reaches the loop header with the loads pending.
+        // the next iteration (gr, the ReLU bits, h4 are first used there) is also a wait for this scatter's sixteen atomics (a load behind
+        // 16 atomics returns after ~1 600 cycles instead of ~1 100: tools/ubench/atomlat.hip).  The use is unconditional on purpose: the
+        // waitcnt pass is path-insensitive, and under the `if` above it still saw a path (loads issued, use skipped) that reaches the
+        // loop header with the loads pending.
         if constexpr (SAVED) asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
         NSK_PH(17); NSK_PHI(17);
         if (scat) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <iostream>
 #include "inputs/CoFusionReader.h"
+#include "inputs/SequenceReader.h"
 #include "Renderer.h"
 #include <yaml-cpp/yaml.h>
 
@@ -13,6 +14,9 @@ class Tracker {
     void run(NICE decoders, torch::Tensor gt_color_t, torch::Tensor gt_depth_t, torch::Tensor gt_c2w_t, int idx);
     // src/main.cpp:96 (D1): every frame of the reader through the 5-argument form; frames_limit < 0 = until reader.hasMore() is false
     void run(CoFusionReader& reader, NICE decoders);
+    // the same loop over a posed sequence (Replica / ScanNet / TUM layouts, inputs/SequenceReader.h: not in the reference); the reader's
+    // pose of each frame is passed as gt_c2w
+    void run(SequenceReader& reader, NICE decoders);
     int frames_limit = -1;
     torch::Tensor optimize_cam_in_batch(torch::Tensor cam_tensor, torch::Tensor gt_color, torch::Tensor gt_depth, int batch_size,
                                         torch::optim::Adam& optimizer, NICE decoders);

@@ -614,6 +614,21 @@ void Tracker::run(CoFusionReader& reader, NICE decoders)                        
     }
 }
 
+void Tracker::run(SequenceReader& reader, NICE decoders)
+{
+    int n = 0;
+    while (reader.hasMore() && (frames_limit < 0 || n < frames_limit)) {
+        const int frame = reader.getIdx();
+        reader.getNext();
+        torch::Tensor depth_t = torch::from_blob(reader.depth.data, {reader.depth.rows, reader.depth.cols}, torch::kFloat32).clone();
+        torch::Tensor color_t = torch::from_blob(reader.rgb.data, {reader.rgb.rows, reader.rgb.cols, reader.rgb.channels()}, torch::kFloat32).clone();
+        torch::Tensor c2w_t = torch::zeros({4, 4});
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c2w_t[i][j] = reader.c2w(i, j);
+        run(decoders, color_t, depth_t, c2w_t, frame);
+        ++n;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Mapper
 // ---------------------------------------------------------------------------------------------------------

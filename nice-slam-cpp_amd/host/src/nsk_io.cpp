@@ -301,3 +301,152 @@ void CoFusionReader::getNext()                                  // :36-60
     depth.convertTo(depth, CV_32FC1);            // :51
     fptr++;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// SequenceReader: Replica / ScanNet / TUM-RGBD layouts (inputs/SequenceReader.h)
+// ---------------------------------------------------------------------------------------------------------
+#include "inputs/SequenceReader.h"
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <sstream>
+
+namespace {
+bool file_exists(const std::string& p) { std::ifstream f(p, std::ios::binary); return f.good(); }
+
+std::string with_ext(const std::string& stem)
+{
+    for (const char* e : {".png", ".jpg", ".jpeg"}) if (file_exists(stem + e)) return stem + e;
+    return std::string();
+}
+
+Eigen::Matrix4f to_opengl(Eigen::Matrix4f m)      // camera y and z axes negated (upstream NICE-SLAM datasets: c2w[:3, 1] *= -1, c2w[:3, 2] *= -1)
+{
+    for (int i = 0; i < 3; ++i) { m(i, 1) = -m(i, 1); m(i, 2) = -m(i, 2); }
+    return m;
+}
+
+Eigen::Matrix4f read_4x4(std::istream& in, const std::string& what)
+{
+    Eigen::Matrix4f m;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double v; if (!(in >> v)) throw std::runtime_error("SequenceReader: " + what + ": 16 numbers expected"); m(i, j) = (float)v; }
+    return m;
+}
+
+struct Stamped { double t; std::string rest; };
+std::vector<Stamped> read_stamped(const std::string& path)
+{
+    std::ifstream f(path);
+    if (!f.good()) throw std::runtime_error("SequenceReader: cannot read " + path);
+    std::vector<Stamped> v;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        Stamped s;
+        if (!(ss >> s.t)) continue;
+        std::getline(ss, s.rest);
+        size_t a = s.rest.find_first_not_of(" \t"); s.rest = a == std::string::npos ? std::string() : s.rest.substr(a);
+        while (!s.rest.empty() && (s.rest.back() == '\r' || s.rest.back() == ' ')) s.rest.pop_back();
+        v.push_back(s);
+    }
+    return v;
+}
+
+int nearest(const std::vector<Stamped>& v, double t)
+{
+    int best = -1; double bd = 1e300;
+    for (size_t i = 0; i < v.size(); ++i) { const double d = std::fabs(v[i].t - t); if (d < bd) { bd = d; best = (int)i; } }
+    return best;
+}
+
+Eigen::Matrix4f pose_from_tq(const std::string& rest)      // "tx ty tz qx qy qz qw" -> camera-to-world
+{
+    std::istringstream ss(rest);
+    double t[3], q[4];
+    if (!(ss >> t[0] >> t[1] >> t[2] >> q[0] >> q[1] >> q[2] >> q[3])) throw std::runtime_error("SequenceReader: groundtruth.txt: 7 numbers expected after the timestamp");
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+    Eigen::Matrix4f m = Eigen::Matrix4f::Identity();
+    m(0, 0) = (float)(1 - 2 * (y * y + z * z)); m(0, 1) = (float)(2 * (x * y - z * w)); m(0, 2) = (float)(2 * (x * z + y * w));
+    m(1, 0) = (float)(2 * (x * y + z * w)); m(1, 1) = (float)(1 - 2 * (x * x + z * z)); m(1, 2) = (float)(2 * (y * z - x * w));
+    m(2, 0) = (float)(2 * (x * z - y * w)); m(2, 1) = (float)(2 * (y * z + x * w)); m(2, 2) = (float)(1 - 2 * (x * x + y * y));
+    for (int i = 0; i < 3; ++i) m(i, 3) = (float)t[i];
+    return m;
+}
+}  // namespace
+
+SequenceReader::SequenceReader(Kind k, std::string inp, float tum_frame_rate) : kind(k), input_folder(inp), width(0), height(0), fptr(0)
+{
+    if (!input_folder.empty() && input_folder.back() != '/') input_folder += '/';
+    c2w = Eigen::Matrix4f::Identity();
+    if (kind == Replica) {
+        png_depth_scale = 6553.5f;
+        std::ifstream tr(input_folder + "traj.txt");
+        if (!tr.good()) throw std::runtime_error("SequenceReader: cannot read " + input_folder + "traj.txt");
+        for (int i = 0;; ++i) {
+            char num[16]; std::snprintf(num, sizeof(num), "%06d", i);
+            const std::string d = input_folder + "results/depth" + num + ".png";
+            if (!file_exists(d)) break;
+            const std::string cfile = with_ext(input_folder + "results/frame" + num);
+            if (cfile.empty()) throw std::runtime_error("SequenceReader: no colour image for " + d);
+            depth_files.push_back(d); color_files.push_back(cfile);
+            poses.push_back(to_opengl(read_4x4(tr, "traj.txt")));
+        }
+    } else if (kind == ScanNet) {
+        png_depth_scale = 1000.f;
+        for (int i = 0;; ++i) {
+            const std::string d = input_folder + "depth/" + std::to_string(i) + ".png";
+            if (!file_exists(d)) break;
+            const std::string cfile = with_ext(input_folder + "color/" + std::to_string(i));
+            if (cfile.empty()) throw std::runtime_error("SequenceReader: no colour image for " + d);
+            std::ifstream pf(input_folder + "pose/" + std::to_string(i) + ".txt");
+            if (!pf.good()) throw std::runtime_error("SequenceReader: no pose file for " + d);
+            depth_files.push_back(d); color_files.push_back(cfile);
+            poses.push_back(to_opengl(read_4x4(pf, "pose/" + std::to_string(i) + ".txt")));
+        }
+    } else {
+        png_depth_scale = 5000.f;
+        const std::vector<Stamped> rgbs = read_stamped(input_folder + "rgb.txt"), deps = read_stamped(input_folder + "depth.txt"),
+                                   gts = read_stamped(input_folder + "groundtruth.txt");
+        const double max_dt = 0.08;
+        double last_t = -1e300;
+        bool have_first = false;
+        Eigen::Matrix4f inv0 = Eigen::Matrix4f::Identity();
+        for (const Stamped& r : rgbs) {
+            const int j = nearest(deps, r.t), k = nearest(gts, r.t);
+            if (j < 0 || k < 0 || std::fabs(deps[j].t - r.t) >= max_dt || std::fabs(gts[k].t - r.t) >= max_dt) continue;
+            if (have_first && r.t - last_t <= 1.0 / tum_frame_rate) continue;          // thinned to frame_rate Hz
+            Eigen::Matrix4f p = pose_from_tq(gts[k].rest);
+            if (!have_first) { inv0 = p.inverse(); have_first = true; }
+            last_t = r.t;
+            color_files.push_back(input_folder + r.rest); depth_files.push_back(input_folder + deps[j].rest);
+            poses.push_back(to_opengl(inv0 * p));
+        }
+    }
+    n_imgs = (int)depth_files.size();
+    if (n_imgs == 0) throw std::runtime_error("SequenceReader: no frames found under " + input_folder);
+}
+SequenceReader::~SequenceReader() {}
+bool SequenceReader::hasMore() { return fptr < n_imgs; }
+int SequenceReader::getIdx() { return fptr; }
+void SequenceReader::getBack() { if (fptr > 0) --fptr; }
+void SequenceReader::reset() { fptr = 0; }
+
+void SequenceReader::getNext()
+{
+    if (!hasMore()) { std::cout << fptr << "! fptr size exceeded." << std::endl; return; }
+    const std::string& cf = color_files[fptr];
+    rgb = cv::imread(cf, cv::IMREAD_COLOR);
+    if (rgb.empty()) {
+        const bool jpg = cf.size() > 4 && (cf.substr(cf.size() - 4) == ".jpg" || cf.substr(cf.size() - 5) == ".jpeg");
+        throw std::runtime_error("SequenceReader: cannot read " + cf + (jpg ? " (the cv::imread stand-in decodes PNG only: build against OpenCV or convert the colour images to PNG)" : ""));
+    }
+    cv::Mat d16 = cv::imread(depth_files[fptr], cv::IMREAD_UNCHANGED);
+    if (d16.empty() || d16.channels() != 1) throw std::runtime_error("SequenceReader: cannot read " + depth_files[fptr] + " as a one-channel depth image");
+    rgb.convertTo(rgb, CV_32FC3, 1.0 / 255.0);
+    d16.convertTo(depth, CV_32FC1, 1.0 / png_depth_scale);
+    width = depth.cols; height = depth.rows;
+    c2w = poses[fptr];
+    fptr++;
+}

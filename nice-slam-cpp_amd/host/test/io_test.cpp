@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "inputs/CoFusionReader.h"
+#include "inputs/SequenceReader.h"
 
 static void save_npy(const std::string& path, const float* data, const std::vector<int>& shape)
 {
@@ -74,6 +75,30 @@ int main(int argc, char** argv)
                 ++n;
             }
             if (n != 2 || r.getIdx() != 5 || r.c2w(0, 0) != 1.f || r.c2w(0, 1) != 0.f || r.width != 8 || r.height != 6) { std::fprintf(stderr, "reader state wrong\n"); return 1; }
+        }
+        // the posed-sequence readers (Replica / ScanNet / TUM layouts): every frame's colour, metric depth and OpenGL pose
+        {
+            const struct { SequenceReader::Kind kind; const char* dir; } sets[3] = {{SequenceReader::Replica, "replica"}, {SequenceReader::ScanNet, "scannet"}, {SequenceReader::TUM, "tum"}};
+            for (const auto& st : sets) {
+                SequenceReader r(st.kind, d + st.dir, 10.f);
+                std::vector<float> P;
+                int n = 0;
+                while (r.hasMore()) {
+                    const int idx = r.getIdx();
+                    r.getNext();
+                    save_mat(d + "out_" + st.dir + "_depth" + std::to_string(idx) + ".npy", r.depth);
+                    save_mat(d + "out_" + st.dir + "_rgb" + std::to_string(idx) + ".npy", r.rgb);
+                    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) P.push_back(r.c2w(i, j));
+                    ++n;
+                }
+                if (n != r.n_imgs || (int)r.poses.size() != n) { std::fprintf(stderr, "%s: frame count\n", st.dir); return 1; }
+                save_npy(d + "out_" + st.dir + "_poses.npy", P.data(), {n, 4, 4});
+                r.reset();
+                if (!r.hasMore() || r.getIdx() != 0) return 1;
+            }
+            bool threw = false;
+            try { SequenceReader bad(SequenceReader::Replica, d + "replica_jpg"); bad.getNext(); } catch (const std::exception& e) { threw = std::string(e.what()).find("PNG only") != std::string::npos; }
+            if (!threw) { std::fprintf(stderr, "a JPEG colour image must be refused with a clear message\n"); return 1; }
         }
         std::printf("io_test ok\n");
         return 0;

@@ -124,6 +124,74 @@ def _exr(path, channels, compression, xmin=0, ymin=0):
         f.write(hdr + b"".join(struct.pack("<Q", o) for o in offs) + body)
 
 
+POSED = None
+
+
+def _rand_pose(rng):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    m = np.eye(4); m[:3, :3] = R; m[:3, 3] = rng.uniform(-2, 2, 3)
+    return m, q
+
+
+def _write_posed_sequences(d, rng):
+    """tiny Replica / ScanNet / TUM-RGBD sequences in the upstream NICE-SLAM layouts (PNG colour); returns what the readers must hand out"""
+    want = {}
+    H, W = 6, 8
+    # Replica: results/frame%06d.png, results/depth%06d.png (/6553.5), traj.txt
+    rd = os.path.join(d, "replica"); os.makedirs(os.path.join(rd, "results"))
+    fr = []
+    with open(os.path.join(rd, "traj.txt"), "w") as f:
+        for i in range(3):
+            col = rng.integers(0, 256, (H, W, 3), dtype=np.uint8); dep = rng.integers(0, 65536, (H, W)).astype(np.uint16); m, _ = _rand_pose(rng)
+            _png(os.path.join(rd, "results", "frame%06d.png" % i), col); _png(os.path.join(rd, "results", "depth%06d.png" % i), dep)
+            f.write(" ".join("%.9g" % v for v in m.reshape(-1)) + "\n")
+            fr.append((col, dep.astype(np.float32) / np.float32(6553.5), m))
+    want["replica"] = fr
+    # a Replica frame whose colour image is a JPEG: the stand-in must refuse it with a clear message
+    rj = os.path.join(d, "replica_jpg"); os.makedirs(os.path.join(rj, "results"))
+    _png(os.path.join(rj, "results", "depth000000.png"), np.zeros((H, W), np.uint16))
+    open(os.path.join(rj, "results", "frame000000.jpg"), "wb").write(b"\xff\xd8\xff\xe0 not decoded here")
+    open(os.path.join(rj, "traj.txt"), "w").write("1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1\n")
+    # ScanNet: color/%d.png, depth/%d.png (/1000), pose/%d.txt
+    sd = os.path.join(d, "scannet")
+    for sub in ("color", "depth", "pose"):
+        os.makedirs(os.path.join(sd, sub))
+    fr = []
+    for i in range(2):
+        col = rng.integers(0, 256, (H, W, 3), dtype=np.uint8); dep = rng.integers(0, 8000, (H, W)).astype(np.uint16); m, _ = _rand_pose(rng)
+        _png(os.path.join(sd, "color", "%d.png" % i), col); _png(os.path.join(sd, "depth", "%d.png" % i), dep)
+        open(os.path.join(sd, "pose", "%d.txt" % i), "w").write("\n".join(" ".join("%.9g" % v for v in row) for row in m) + "\n")
+        fr.append((col, dep.astype(np.float32) / np.float32(1000.0), m))
+    want["scannet"] = fr
+    # TUM: stamped lists; rgb frames at 0.00, 0.03 (too close at 10 Hz: dropped), 0.15, 0.30 (no depth within 0.08 s: dropped), 0.45
+    td = os.path.join(d, "tum"); os.makedirs(os.path.join(td, "rgb")); os.makedirs(os.path.join(td, "depth"))
+    stamps = [0.00, 0.03, 0.15, 0.30, 0.45]
+    dstamps = [0.01, 0.04, 0.16, 0.40, 0.46]
+    cols, deps, gts = [], [], []
+    with open(os.path.join(td, "rgb.txt"), "w") as f:
+        f.write("# color images\n# timestamp filename\n")
+        for t in stamps:
+            col = rng.integers(0, 256, (H, W, 3), dtype=np.uint8); cols.append(col)
+            _png(os.path.join(td, "rgb", "%.6f.png" % t), col); f.write("%.6f rgb/%.6f.png\n" % (t, t))
+    with open(os.path.join(td, "depth.txt"), "w") as f:
+        f.write("# depth maps\n")
+        for t in dstamps:
+            dep = rng.integers(0, 30000, (H, W)).astype(np.uint16); deps.append(dep)
+            _png(os.path.join(td, "depth", "%.6f.png" % t), dep); f.write("%.6f depth/%.6f.png\n" % (t, t))
+    with open(os.path.join(td, "groundtruth.txt"), "w") as f:
+        f.write("# ground truth trajectory\n# timestamp tx ty tz qx qy qz qw\n")
+        for t in [0.005, 0.035, 0.155, 0.305, 0.455]:
+            m, q = _rand_pose(rng); gts.append(m)
+            f.write("%.6f %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n" % ((t,) + tuple(m[:3, 3]) + tuple(q)))
+    keep = [0, 2, 4]                                             # rgb indices that survive; their depth / pose partners have the same index
+    inv0 = np.linalg.inv(gts[0])
+    want["tum"] = [(cols[i], deps[i].astype(np.float32) / np.float32(5000.0), inv0 @ gts[i]) for i in keep]
+    return want
+
+
 @pytest.fixture(scope="module")
 def io_dump(tmp_path_factory):
     subprocess.check_call(["make", "-s", "-C", HOST, "all"])
@@ -150,6 +218,8 @@ def io_dump(tmp_path_factory):
         _png(os.path.join(seq, "colour", "Color0%03d.png" % idx), col)
         _exr(os.path.join(seq, "depth_noise", "Depth0%03d.exr" % idx), [("R", "float", dep), ("G", "float", dep * 2), ("B", "float", dep * 3)], 3)
         seq_fx[idx] = (col, dep)
+    global POSED
+    POSED = _write_posed_sequences(d, rng)
     r = subprocess.run([EXE, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     out = {f[4:-4]: np.load(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("out_")}
@@ -225,3 +295,19 @@ def test_reference_main_compiles_unchanged_against_the_drop_in_headers():
     nm = subprocess.run(["nm", "-D", "--undefined-only", "-C", main_ref], capture_output=True, text=True).stdout
     for sym in ("Tracker::run(CoFusionReader&, NICE)", "Tracker::Tracker(", "NICE::NICE(", "CoFusionReader::CoFusionReader("):
         assert sym in nm, sym
+
+
+@pytest.mark.parametrize("name", ["replica", "scannet", "tum"])
+def test_posed_sequence_readers(io_dump, name):
+    """inputs/SequenceReader.h (the readers BASELINE.json's K2-K5 presuppose and the reference lacks): colour / 255 in B,G,R order, depth in
+    metres (png / 6553.5, 1000, 5000), poses as OpenGL cameras (columns 1 and 2 negated); TUM: rgb stamps associated with depth and pose
+    within 0.08 s, thinned to the frame rate, poses relative to the first frame"""
+    out = io_dump[0]
+    want = POSED[name]
+    poses = out[name + "_poses"]
+    assert poses.shape == (len(want), 4, 4)
+    for i, (col, dep, m) in enumerate(want):
+        assert np.allclose(out["%s_rgb%d" % (name, i)], col[:, :, ::-1].astype(np.float32) / 255.0, atol=1e-7)
+        assert np.allclose(out["%s_depth%d" % (name, i)], dep, rtol=1e-6, atol=1e-7)
+        gl = m.copy(); gl[:3, 1] *= -1; gl[:3, 2] *= -1
+        assert np.allclose(poses[i], gl, atol=2e-6), (name, i)

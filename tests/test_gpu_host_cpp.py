@@ -160,3 +160,113 @@ def test_mapper_window_is_ranked_by_overlap(dump, oracle32):
     ref = oracle32.keyframe_overlap(ro, rd, dump["map_depth_img"].reshape(-1), (fx, fy, cx, cy), (H, W), poses[:4])
     assert ref[1] == 0 and pct[1] == 0 and ref[0] > ref[2] > ref[3] > 0        # opposite view never overlaps
     assert np.abs(pct - ref).max() < 0.08, (pct, ref)
+
+
+NS_YAML = """coarse: True
+grid_len:
+  coarse: 2.0
+  middle: 0.32
+  fine: 0.16
+  color: 0.16
+tracking:
+  ignore_edge_W: 4
+  ignore_edge_H: 4
+  use_color_in_tracking: True
+  handle_dynamic: True
+  w_color_loss: 0.5
+  lr: 0.001
+  pixels: 200
+  iters: 5
+mapping:
+  color_refine: True
+  middle_iter_ratio: 0.4
+  fine_iter_ratio: 0.6
+  BA: False
+  BA_cam_lr: 0.001
+  fix_fine: True
+  fix_color: False
+  keyframe_every: 2
+  mapping_window_size: 5
+  w_color_loss: 0.2
+  frustum_feature_selection: True
+  keyframe_selection_method: 'overlap'
+  lr_first_factor: 5
+  lr_factor: 1
+  pixels: 500
+  iters_first: 30
+  iters: 10
+  stage:
+    coarse:
+      decoders_lr: 0.0
+      coarse_lr: 0.001
+      middle_lr: 0.0
+      fine_lr: 0.0
+      color_lr: 0.0
+    middle:
+      decoders_lr: 0.0
+      coarse_lr: 0.0
+      middle_lr: 0.1
+      fine_lr: 0.0
+      color_lr: 0.0
+    fine:
+      decoders_lr: 0.0
+      coarse_lr: 0.0
+      middle_lr: 0.005
+      fine_lr: 0.005
+      color_lr: 0.0
+    color:
+      decoders_lr: 0.005
+      coarse_lr: 0.0
+      middle_lr: 0.005
+      fine_lr: 0.005
+      color_lr: 0.005
+"""
+
+
+def test_slam_loop_over_a_tum_sequence(tmp_path):
+    """K5's frame loop through the C++ classes: SequenceReader (TUM layout) -> Tracker::run on every frame -> Mapper::run (keyframes,
+    overlap window, frustum masks) on every frame, five frames of a synthetic sequence rendered from the analytic room and written as
+    16-bit depth / 8-bit colour PNGs with TUM stamp files.  The decoders are random (no pretrained weights exist offline), so this
+    checks that the loop runs end to end on the device and stays sane -- finite losses, a falling mapping loss on the first frame's
+    30 iterations vs its later ones is not asserted -- poses that stay within centimetres of the truth the Tracker was started near."""
+    from test_host_io import _png
+    exe = os.path.join(ROOT, "nice-slam-cpp_amd", "host", "slam_loop")
+    if not os.path.exists(exe):
+        pytest.fail("slam_loop is not built (run __graft_entry__.build())")
+    seq = tmp_path / "tum"
+    (seq / "rgb").mkdir(parents=True); (seq / "depth").mkdir()
+    H, W, fx, fy, cx, cy = 48, 64, 40.0, 40.0, 32.0, 24.0
+    bound = np.array([[-2.0, 2.0], [-1.5, 1.5], [-2.0, 2.2]], np.float32)
+    flip = np.diag([1.0, -1.0, -1.0, 1.0])
+    gts = []
+    with open(seq / "rgb.txt", "w") as fr, open(seq / "depth.txt", "w") as fd, open(seq / "groundtruth.txt", "w") as fg:
+        for i in range(5):
+            t = 1.0 + 0.1 * i
+            p_tum = np.eye(4); p_tum[:3, 3] = [0.02 * i, 0.01 * i, 0.015 * i]          # TUM convention; frame 0 = identity (poses are relative to it)
+            c2w = (p_tum @ flip).astype(np.float32)                                   # the OpenGL camera the reader hands out
+            gts.append(c2w)
+            depth = scenes.frame_depth_image(bound, c2w, H, W, fx, fy, cx, cy)
+            jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+            dirs = np.stack([(ii - cx) / fx, -(jj - cy) / fy, -np.ones_like(ii, dtype=np.float64)], -1) @ c2w[:3, :3].T.astype(np.float64)
+            hit = c2w[:3, 3] + dirs * depth[..., None]
+            col = np.clip(255 * (0.5 + 0.5 * np.sin(hit * np.array([1.3, 2.1, 0.7]))), 0, 255).astype(np.uint8)
+            _png(str(seq / "rgb" / ("%.6f.png" % t)), col)
+            _png(str(seq / "depth" / ("%.6f.png" % t)), np.round(depth * 5000).astype(np.uint16))
+            fr.write("%.6f rgb/%.6f.png\n" % (t, t)); fd.write("%.6f depth/%.6f.png\n" % (t, t))
+            fg.write("%.6f %.9g %.9g %.9g 0 0 0 1\n" % ((t,) + tuple(p_tum[:3, 3])))
+    (seq / "bound.txt").write_text(" ".join("%g" % v for v in bound.reshape(-1)))
+    ns, cf = tmp_path / "ns.yaml", tmp_path / "cf.yaml"
+    ns.write_text(NS_YAML)
+    cf.write_text("mapping:\n  pixels: 500\ncam:\n  H: %d\n  W: %d\n  fx: %g\n  fy: %g\n  cx: %g\n  cy: %g\n" % (H, W, fx, fy, cx, cy))
+    out = tmp_path / "out"; out.mkdir()
+    r = subprocess.run([exe, "tum", str(seq), str(ns), str(cf), str(out), "5", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "slam_loop ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    est, gt = np.load(out / "est_poses.npy"), np.load(out / "gt_poses.npy")
+    assert est.shape == (5, 4, 4) and np.allclose(gt, np.stack(gts), atol=1e-5)                     # the reader's poses are the ones written
+    tl, ml = np.load(out / "track_loss.npy"), np.load(out / "map_loss.npy")
+    assert tl.shape == (5,) and ml.shape == (5,) and np.isfinite(tl).all() and np.isfinite(ml).all() and (ml > 0).all() and (tl[1:] > 0).all()
+    assert np.isfinite(est).all()
+    assert np.linalg.norm(est[:, :3, 3] - gt[:, :3, 3], axis=1).max() < 0.15                        # started from the previous estimate, 5 small steps
+    for k in ("grid_middle", "grid_fine", "grid_color"):
+        g = np.load(out / (k + ".npy"))
+        assert np.isfinite(g).all() and np.abs(g).max() > 0.02                                     # the map moved away from its N(0, 0.01) init

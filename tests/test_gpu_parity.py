@@ -571,6 +571,16 @@ def test_prepare_rays_equals_the_separate_entry_points():
         for name, a, b in (("pix_i", got["pix_i"][sl], pi), ("pix_j", got["pix_j"][sl], pj), ("gt_depth", got["gt_depth"][sl], gd), ("gt_color", got["gt_color"][sl], gc),
                            ("rays_o", got["rays_o"][sl], ro), ("rays_d", got["rays_d"][sl], rd), ("keep", got["keep"][sl].bool(), keep)):
             assert torch.equal(a.cpu().reshape(-1), b.cpu().reshape(-1)), (k, name)
+    # more frames than one launch's table holds (16): the call splits, outputs stay frame-major
+    many = [dict(depth=frames[k % 2]["depth"], color=frames[k % 2]["color"], pose=frames[k % 2]["pose"], seed=5000 + k) for k in range(19)]
+    got = ctx.prepare_rays(many, 40, win, intr)
+    ctx.sync()
+    for k in (0, 15, 16, 18):
+        pi, pj = ctx.sample_pixels(5000 + k, 40, *win)
+        gd, _ = ctx.gather_pixels(pi, pj, many[k]["depth"], many[k]["color"])
+        ctx.sync()
+        sl = slice(k * 40, (k + 1) * 40)
+        assert torch.equal(got["pix_i"][sl].cpu(), pi.cpu()) and torch.equal(got["gt_depth"][sl].cpu(), gd.cpu()), k
     ctx.close()
 
 

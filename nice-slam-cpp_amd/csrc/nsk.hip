@@ -181,6 +181,23 @@ __global__ void k_grad_scatter(int n, const int* __restrict__ idx, const float* 
     reinterpret_cast<f4*>(g)[(size_t)v * 8 + (t & 7)] = reinterpret_cast<const f4*>(packed)[t];
 }
 
+// the whole packed exchange buffer in ONE launch each way (it was one launch per level plus two copies: eleven small operations per
+// step around the all-reduce): segments = grid levels (32 floats per listed voxel), trainable decoders and the loss scalars (plain runs)
+struct XSeg { const int* idx; int n4; float* slab; float* buf; int blk_end; };     // n4 = float4 count of the segment; idx != nullptr: voxel list, 8 float4 per voxel
+struct XArgs { XSeg s[10]; int n; int gather; };
+__global__ __launch_bounds__(256) void k_xchg_multi(XArgs A)
+{
+    int r = 0;
+    while (r < A.n - 1 && (int)blockIdx.x >= A.s[r].blk_end) ++r;
+    const XSeg& S = A.s[r];
+    const int t = (blockIdx.x - (r ? A.s[r - 1].blk_end : 0)) * 256 + threadIdx.x;
+    if (t >= S.n4) return;
+    const size_t at = S.idx ? (size_t)S.idx[t >> 3] * 8 + (t & 7) : (size_t)t;
+    f4* sl = reinterpret_cast<f4*>(S.slab) + at;
+    f4* bf = reinterpret_cast<f4*>(S.buf) + t;
+    if (A.gather) *bf = *sl; else *sl = *bf;
+}
+
 struct PackSeg { float* img; const int* idx; const float* P; int n; int blk_end; };
 struct PackArgs { PackSeg s[8]; int n; };
 __global__ void k_pack_multi(PackArgs A)
@@ -2270,27 +2287,30 @@ static int pack_layout(nsk_ctx* c, size_t* total)
 
 static int pack_move(nsk_ctx* c, bool gather)
 {
+    XArgs A;
+    memset(&A, 0, sizeof(A));
+    A.gather = gather ? 1 : 0;
     size_t o = 0;
+    int blocks = 0;
+    auto add = [&](const int* idx, size_t n4, float* slab) {
+        if (n4 == 0) return;
+        XSeg& S = A.s[A.n++];
+        S.idx = idx; S.n4 = (int)n4; S.slab = slab; S.buf = c->xbuf + o;
+        blocks += (int)((n4 + 255) / 256); S.blk_end = blocks;
+        o += n4 * 4;
+    };
     for (int l = 0; l < 4; ++l) {
         if (!c->xlevels[l]) continue;
         GridState& G = c->grid[l];
         const int nv = G.mask ? G.nmask : (int)(G.n / 32);
-        if (nv > 0) {
-            const int blocks = (nv * 8 + 255) / 256;
-            if (gather) k_grad_gather<<<blocks, 256, 0, c->stream>>>(nv, G.mask ? G.midx : nullptr, c->slab + G.g_off, c->xbuf + o);
-            else k_grad_scatter<<<blocks, 256, 0, c->stream>>>(nv, G.mask ? G.midx : nullptr, c->xbuf + o, c->slab + G.g_off);
-        }
-        o += (size_t)nv * 32;
+        add(G.mask ? G.midx : nullptr, (size_t)nv * 8, c->slab + G.g_off);
     }
     for (int w = 0; w < 4; ++w) {
         if (!c->xdecs[w]) continue;
-        const size_t n4 = (size_t)((c->dec[w].n + 3) & ~3);
-        if (gather) HIPCHK(hipMemcpyAsync(c->xbuf + o, c->slab + c->dec[w].g_off, n4 * 4, hipMemcpyDeviceToDevice, c->stream));
-        else HIPCHK(hipMemcpyAsync(c->slab + c->dec[w].g_off, c->xbuf + o, n4 * 4, hipMemcpyDeviceToDevice, c->stream));
-        o += n4;
+        add(nullptr, (size_t)((c->dec[w].n + 3) & ~3) / 4, c->slab + c->dec[w].g_off);
     }
-    if (gather) HIPCHK(hipMemcpyAsync(c->xbuf + o, c->slab + c->slab_n - 4, 16, hipMemcpyDeviceToDevice, c->stream));
-    else HIPCHK(hipMemcpyAsync(c->slab + c->slab_n - 4, c->xbuf + o, 16, hipMemcpyDeviceToDevice, c->stream));
+    add(nullptr, 1, c->slab + c->slab_n - 4);                 // loss scalars
+    if (blocks > 0) k_xchg_multi<<<blocks, 256, 0, c->stream>>>(A);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -70,30 +70,23 @@ __global__ void k_adam_multi(AdamArgs A)
     const int b0 = r == 0 ? 0 : A.s[r - 1].blk_end;
     int i = (blockIdx.x - b0) * blockDim.x + threadIdx.x;
     f4 extra = (f4)(0.f);
-    if (S.slabs) {      // decoder whose gradient still sits in per-workgroup slabs: 32 float4 per block, 8 threads sum 1/8 of the slabs each
-        __shared__ f4 red[8][32];
-        const int pi = threadIdx.x & 31, sg = threadIdx.x >> 5;
-        i = (blockIdx.x - b0) * 32 + pi;
-        // four independent partial sums: a thread's ~24 slab reads were one dependent-looking chain of L2 round trips, and this
-        // reduction (not the grids' Adam traffic) was most of the launch's 18 us
-        f4 part = (f4)(0.f), q1 = (f4)(0.f), q2 = (f4)(0.f), q3 = (f4)(0.f);
+    if (S.slabs) {      // decoder whose gradient still sits in per-workgroup slabs: 8 float4 per block, 32 thread groups sum 1/32 of the slabs each
+        // (all of a thread's ~6 slab reads are in flight at once: this sum, not the grids' Adam traffic, was most of the launch's time --
+        // 18 us with 8 groups reading ~24 slabs one after the other, 14 us with four reads in flight, see profiles/)
+        __shared__ f4 red[32][8];
+        const int pi = threadIdx.x & 7, sg = threadIdx.x >> 3;
+        i = (blockIdx.x - b0) * 8 + pi;
+        f4 part = (f4)(0.f);
         if (4 * i < S.n) {
             const float* base = S.slabs + 4 * i;
-            int sl = sg;
-            for (; sl + 24 < S.nslabs; sl += 32) {
-                part += *reinterpret_cast<const f4*>(base + (size_t)sl * S.slab_stride);
-                q1 += *reinterpret_cast<const f4*>(base + (size_t)(sl + 8) * S.slab_stride);
-                q2 += *reinterpret_cast<const f4*>(base + (size_t)(sl + 16) * S.slab_stride);
-                q3 += *reinterpret_cast<const f4*>(base + (size_t)(sl + 24) * S.slab_stride);
-            }
-            for (; sl < S.nslabs; sl += 8) part += *reinterpret_cast<const f4*>(base + (size_t)sl * S.slab_stride);
-            part += q1 + q2 + q3;
+#pragma unroll 8
+            for (int sl = sg; sl < S.nslabs; sl += 32) part += *reinterpret_cast<const f4*>(base + (size_t)sl * S.slab_stride);
         }
         red[sg][pi] = part;
         __syncthreads();
         if (sg != 0) return;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) extra += red[k][pi];
+        for (int k = 0; k < 32; ++k) extra += red[k][pi];
     }
     if (S.idx) {                  // a masked level: the launch covers the marked voxels only (8 float4 each); unmarked ones are never touched
         if (i >= S.nidx * 8) return;
@@ -2108,7 +2101,7 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
             D.bimg16_dirty = true;
             if (c->pend_w == w) {
                 S.slabs = c->ws.dec_slabs; S.nslabs = c->pend_nb; S.slab_stride = n4; c->pend_w = -1;
-                blocks += (n4 / 4 + 31) / 32 - (n4 / 4 + 255) / 256;       // 32 float4 per block (see k_adam_multi)
+                blocks += (n4 / 4 + 7) / 8 - (n4 / 4 + 255) / 256;         // 8 float4 per block (see k_adam_multi)
             }
             if (D.fimg16) { S.inv16 = D.inv16; S.img16 = reinterpret_cast<unsigned short*>(D.fimg16); S.img16_tail = D.fimg16 + D.tail16_off; S.tail_off = D.tail_off; }
             blocks += (n4 / 4 + 255) / 256; S.blk_end = blocks;

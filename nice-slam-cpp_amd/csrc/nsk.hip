@@ -176,14 +176,36 @@ __global__ void k_grad_scatter(int n, const int* __restrict__ idx, const float* 
 
 // the whole packed exchange buffer in ONE launch each way (it was one launch per level plus two copies: eleven small operations per
 // step around the all-reduce): segments = grid levels (32 floats per listed voxel), trainable decoders and the loss scalars (plain runs)
-struct XSeg { const int* idx; int n4; float* slab; float* buf; int blk_end; };     // n4 = float4 count of the segment; idx != nullptr: voxel list, 8 float4 per voxel
+struct XSeg { const int* idx; int n4; float* slab; float* buf; int blk_end;       // n4 = float4 count of the segment; idx != nullptr: voxel list, 8 float4 per voxel
+              const float* slabs; int nslabs, slab_stride; };                     // gather only: a decoder whose gradient still sits in per-workgroup slabs
 struct XArgs { XSeg s[10]; int n; int gather; };
 __global__ __launch_bounds__(256) void k_xchg_multi(XArgs A)
 {
     int r = 0;
     while (r < A.n - 1 && (int)blockIdx.x >= A.s[r].blk_end) ++r;
     const XSeg& S = A.s[r];
-    const int t = (blockIdx.x - (r ? A.s[r - 1].blk_end : 0)) * 256 + threadIdx.x;
+    const int b0 = r ? A.s[r - 1].blk_end : 0;
+    if (S.slabs) {          // the pending decoder-gradient slabs are summed on the way into the buffer (the sum k_adam_multi does on one GPU):
+        __shared__ f4 red[32][8];                 // 8 float4 per block, 32 thread groups sum 1/32 of the slabs each
+        const int pi = threadIdx.x & 7, sg = threadIdx.x >> 3;
+        const int i = (blockIdx.x - b0) * 8 + pi;
+        f4 part = (f4)(0.f);
+        if (i < S.n4) {
+            const float* base = S.slabs + 4 * i;
+#pragma unroll 8
+            for (int sl = sg; sl < S.nslabs; sl += 32) part += *reinterpret_cast<const f4*>(base + (size_t)sl * S.slab_stride);
+        }
+        red[sg][pi] = part;
+        __syncthreads();
+        if (sg != 0 || i >= S.n4) return;
+        f4 sum = reinterpret_cast<const f4*>(S.slab)[i];          // + what earlier calls accumulated
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sum += red[k][pi];
+        reinterpret_cast<f4*>(S.buf)[i] = sum;
+        reinterpret_cast<f4*>(S.slab)[i] = sum;                 // the slab stays what nsk_grid/decoder gradient downloads and a second pack expect
+        return;
+    }
+    const int t = (blockIdx.x - b0) * 256 + threadIdx.x;
     if (t >= S.n4) return;
     const size_t at = S.idx ? (size_t)S.idx[t >> 3] * 8 + (t & 7) : (size_t)t;
     f4* sl = reinterpret_cast<f4*>(S.slab) + at;
@@ -2285,11 +2307,16 @@ static int pack_move(nsk_ctx* c, bool gather)
     A.gather = gather ? 1 : 0;
     size_t o = 0;
     int blocks = 0;
-    auto add = [&](const int* idx, size_t n4, float* slab) {
+    auto add = [&](const int* idx, size_t n4, float* slab, int pend_w = -1) {
         if (n4 == 0) return;
         XSeg& S = A.s[A.n++];
         S.idx = idx; S.n4 = (int)n4; S.slab = slab; S.buf = c->xbuf + o;
-        blocks += (int)((n4 + 255) / 256); S.blk_end = blocks;
+        if (gather && pend_w >= 0 && c->pend_w == pend_w) {      // its gradient is still in the backward's per-workgroup slabs: summed by this launch
+            S.slabs = c->ws.dec_slabs; S.nslabs = c->pend_nb; S.slab_stride = (int)(n4 * 4);
+            blocks += (int)((n4 + 7) / 8);
+            c->pend_w = -1;
+        } else blocks += (int)((n4 + 255) / 256);
+        S.blk_end = blocks;
         o += n4 * 4;
     };
     for (int l = 0; l < 4; ++l) {
@@ -2300,7 +2327,7 @@ static int pack_move(nsk_ctx* c, bool gather)
     }
     for (int w = 0; w < 4; ++w) {
         if (!c->xdecs[w]) continue;
-        add(nullptr, (size_t)((c->dec[w].n + 3) & ~3) / 4, c->slab + c->dec[w].g_off);
+        add(nullptr, (size_t)((c->dec[w].n + 3) & ~3) / 4, c->slab + c->dec[w].g_off, w);
     }
     add(nullptr, 1, c->slab + c->slab_n - 4);                 // loss scalars
     if (blocks > 0) k_xchg_multi<<<blocks, 256, 0, c->stream>>>(A);
@@ -2312,12 +2339,12 @@ extern "C" int nsk_grad_pack(nsk_ctx* c, float** p, size_t* n)
 {
     if (!c || !p || !n) return fail("nsk_grad_pack: null argument");
     HIPCHK(hipSetDevice(c->device));
-    CHK(flush_pending(c));
     size_t total = 0;
     CHK(pack_layout(c, &total));
     bool any_mask = false;
     for (int l = 0; l < 4; ++l) any_mask = any_mask || (c->xlevels[l] && c->grid[l].mask);
     if (!any_mask) {                                   // nothing to compact: exchange the slab in place (no copies); unpack is then a no-op
+        CHK(flush_pending(c));
         c->xbuf_n = 0; c->x_identity = true;
         *p = c->slab; *n = c->slab_n;
         return 0;

@@ -69,7 +69,9 @@ void* nsk_stream(nsk_ctx* ctx);                     /* the hipStream_t in use */
 int nsk_set_matmul_mode(nsk_ctx* ctx, int mode);
 
 /* Order in which the decoder kernels of a step walk the rays' samples (results differ only by the order of floating-point sums in the
- * gradients): -1 = automatic (DEFAULT: cell-sorted for steps that scatter into the grids without ray gradients and have >= 2048 samples),
+ * gradients): -1 = automatic (DEFAULT: cell-sorted for steps that scatter into the grids without ray gradients and have >= 14336 samples -- about
+ * 300 rays x 48, the measured crossover on the reference's grids: below it the two sort launches cost more than the scatter saves -- or at
+ * least four samples per cell of the finest level read, where ray order serialises the atomics of the many samples that share a cell),
  * 0 = ray order always, 1 = cell-sorted always.  Cell-sorted: k_sample also bins every sample by the grid cell it falls in and two small
  * launches build the permutation; tiles of 16 samples then share cells and the backward issues one atomic flush per cell run. */
 int nsk_set_sort_mode(nsk_ctx* ctx, int mode);

@@ -1542,10 +1542,18 @@ static void account(nsk_ctx* c, int stage, int M, int N, bool bwd, unsigned flag
 // sampling + decoders of the stage; leaves z / occ / rgb4 (and ReLU bits) in the workspace
 // The cell sort pays when the step scatters into the grids and does not need per-ray gradient sums (those rely on a tile's 16
 // samples sharing a ray: the Tracker and bundle adjustment keep the ray order)
-static bool sort_pays(nsk_ctx* c, int M, unsigned flags)
+static bool sort_pays(nsk_ctx* c, int stage, int M, unsigned flags)
 {
     if (c->deterministic) return false;          // (the cell sort's ranks come from atomics in arrival order)
-    return c->sort_mode == 1 ? true : (c->sort_mode == 0 ? false : ((flags & NSK_GRAD_GRIDS) && !(flags & NSK_GRAD_RAYS) && M >= 2048));
+    if (c->sort_mode >= 0) return c->sort_mode == 1;
+    if (!(flags & NSK_GRAD_GRIDS) || (flags & NSK_GRAD_RAYS)) return false;
+    // Measured (tools/exp_sort_threshold.py, host_test): on the reference's grids (41 k fine cells) the two extra launches pay from ~300
+    // rays x 48 on (200 rays: 92 us in ray order, 97 us sorted; 1000 rays: 236 against 162 us); on a small grid (792 cells, 9600 samples)
+    // many samples share the few cells, ray order serialises their atomics and sorting wins much earlier (118 against 102 us).
+    int key_level = 0;
+    for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) key_level = std::max(key_level, STAGE_DEC[stage][q] == 3 ? 3 : STAGE_DEC[stage][q]);
+    const long cells = (long)(c->grid[key_level].n / 32);
+    return M >= 14336 || (cells > 0 && (long)M >= 4 * cells);
 }
 
 // sorted: the decoders of this step (forward and the backward that follows) walk the samples cell by cell (see k_sample)
@@ -1744,7 +1752,7 @@ extern "C" int nsk_render_backward(nsk_ctx* c, int stage, int N, const float* ro
     CHK(common_checks(c, stage, N, ro, rd, &S, gt));
     if (!g_rgb || !g_depth) return fail("nsk_render_backward: g_rgb / g_depth is NULL");
     if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_render_backward: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
-    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, N * S, flags)));
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, stage, N * S, flags)));
     CompArgs A;
     comp_args(c, A, stage, N, S, ro, rd);
     A.mode = 1; A.g_rgb = g_rgb; A.g_depth = g_depth; A.g_var = g_var;
@@ -1765,7 +1773,7 @@ extern "C" int nsk_map_step(nsk_ctx* c, int stage, int N, const float* ro, const
     if (use_color && !gtc) return fail("nsk_map_step: use_color needs gt_color");
     CHK(common_checks(c, stage, N, ro, rd, &S, gt));
     if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_map_step: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
-    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, N * S, flags)));
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, stage, N * S, flags)));
     CompArgs A;
     comp_args(c, A, stage, N, S, ro, rd);
     A.mode = 2; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
@@ -1796,7 +1804,7 @@ extern "C" int nsk_track_step(nsk_ctx* c, int stage, int N, const float* ro, con
     if (use_color && !gtc) return fail("nsk_track_step: use_color needs gt_color");
     CHK(common_checks(c, stage, N, ro, rd, &S, gt));
     if ((flags & NSK_GRAD_RAYS) && (!g_ro || !g_rd)) return fail("nsk_track_step: NSK_GRAD_RAYS needs g_rays_o and g_rays_d");
-    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, N * S, flags)));
+    CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, stage, N * S, flags)));
     CompArgs A;
     comp_args(c, A, stage, N, S, ro, rd);
     if (handle_dynamic) {                                      // forward pass for the median (Tracker.cpp:69-70)

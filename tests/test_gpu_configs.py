@@ -431,10 +431,10 @@ def test_raw2outputs_standalone(occupancy, oracle32):
     assert rel_l2(w.cpu().numpy(), wref) < 1e-5 and rel_l2(depth.cpu().numpy(), (wref * z16).sum(1)) < 1e-5
 
 
-@pytest.mark.parametrize("n_rays,sort_mode", [(1, -1), (17, 1), (45, -1), (333, 1)])
+@pytest.mark.parametrize("n_rays,sort_mode", [(1, -1), (17, 1), (45, 1), (301, -1), (333, 1)])
 def test_mapping_step_on_ragged_batches(n_rays, sort_mode, oracle32, oracle64):
     """ragged inputs through the whole mapping step: one ray; ray counts that leave the last 16-sample tile, the last 8-tile panel
-    iteration and the last 16-ray sampling workgroup partly empty; in ray order and in cell-sorted order (45 rays = 2160 samples is
+    iteration and the last 16-ray sampling workgroup partly empty; in ray order and in cell-sorted order (301 rays = 14 448 samples is
     just past the automatic sort threshold).  Loss and every gradient against the oracle, all rays."""
     sc = scenes.make_scene(31, scenes.SMALL_GRID_SHAPES, grid_std=0.05, bias_std=0.1)
     rays = scenes.make_rays(32, n_rays, sc["bound"], n_frames=1, zero_frac=0.0)

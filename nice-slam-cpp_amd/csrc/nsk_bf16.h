@@ -127,7 +127,7 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
     typedef MlpFwdImgB<CQ> I;
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const f4* src = reinterpret_cast<const f4*>(A.img16);
-    for (int i = threadIdx.x; i < I::TOTAL_F / 4; i += 64 * NW) smem[i] = src[i];
+    copy_image_to_lds<64 * NW>(smem, src, I::TOTAL_F / 4);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const bf8* img = reinterpret_cast<const bf8*>(smem);

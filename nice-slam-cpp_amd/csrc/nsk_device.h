@@ -29,6 +29,20 @@ __device__ int nsk_dbg_flags;
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// A workgroup's copy of a fragment image into LDS.  Written as the obvious loop the compiler emits load, s_waitcnt vmcnt(0), ds_write per
+// iteration: eleven L2 round trips one after the other (~4 us) at the start of every decoder launch.  Eight loads in flight per thread.
+template <int NT>
+__device__ __forceinline__ void copy_image_to_lds(f4* __restrict__ dst, const f4* __restrict__ src, int n4)
+{
+    for (int i0 = 0; i0 < n4; i0 += 8 * NT) {
+        f4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT + (int)threadIdx.x; r[u] = i < n4 ? src[i] : (f4)(0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT + (int)threadIdx.x; if (i < n4) dst[i] = r[u]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // scalar helpers that spell out the operation sequence of the reference's libtorch ops for the sampling geometry (it feeds sin(25*x) and
 // ReLU kinks).  They fix the ORDER of operations; they are not contraction barriers: HIP's __fmul_rn / __fadd_rn are plain operators and
@@ -726,7 +740,7 @@ template <int WHICH, int NW = 8>
 __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int nb)
 {
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
-    for (int i = threadIdx.x; i < A.img_f4; i += 64 * NW) smem[i] = A.img[i];
+    copy_image_to_lds<64 * NW>(smem, A.img, A.img_f4);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const float* imgf = reinterpret_cast<const float*>(smem);
@@ -1107,7 +1121,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     float* scratch = smf + IMG_F + wave * 960;                  // per-wave scatter scratch (3840 B)
     {
         const f4* src = B16 ? reinterpret_cast<const f4*>(A.bimg16) : A.bimg;
-        for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = src[i];
+        copy_image_to_lds<512>(smem, src, IMG_F / 4);
     }
     __syncthreads();
     const f4* bimg = smem;

@@ -226,7 +226,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     char* pn = reinterpret_cast<char*>(smf + IMG_F);     // shared panel (plane H; plane M at + PM)
     constexpr int PM = PN_MOFF(CQ);
     float* scratch = smf + IMG_F + wave * 1056;     // per-wave scatter scratch (NSK_SCRATCH_FLOATS <= 1056): the head of plane H, idle between the last phase and phase OUT
-    for (int i = threadIdx.x; i < IMG_F / 4; i += 512) smem[i] = A.bimg[i];
+    copy_image_to_lds<512>(smem, A.bimg, IMG_F / 4);
     __syncthreads();
     const f4* fimg = A.img;                         // !SAVED only: forward fragments from L2
     const float* fimgf = reinterpret_cast<const float*>(fimg);

@@ -171,6 +171,7 @@ def cpu_baseline_aten(sc, rays_list, stage, lr, w_color, seconds):
 
 
 TUNE = []
+PIPELINE = False
 
 
 def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, frustum=True):
@@ -215,6 +216,9 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
         def step(i):
             ro, rd, gd, gc, gmax = batches[i % len(batches)]
             ctx.map_step(stage, ro, rd, gd, gc, gmax, w_color, stage == "color", flags=flags, loss=loss)
+            if PIPELINE and not graph:                           # the next batch's sampling + cell sort on the side stream, beside this step
+                nro, nrd, ngd, _, ngmax = batches[(i + 1) % len(batches)]
+                ctx.map_prepare(stage, nro, nrd, ngd, ngmax, flags=flags)
             if world > 1:                                        # the one exchange of the path: the marked voxels of the touched levels,
                 buf = ctx.grad_pack()                            # the colour decoder's gradient and the loss (nsk_grad_pack)
                 xn[0] = buf.numel()
@@ -303,10 +307,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the K2 / fine-stage / K4-shard lines under 'extras'")
     ap.add_argument("--no-frustum-mask", action="store_true", help="optimise every voxel (mapping.frustum_feature_selection: False)")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step as a captured hipGraph (single GPU)")
+    ap.add_argument("--pipeline", action="store_true", help="sample the next batch on the side stream (nsk_map_prepare); measured slower on one "
+                    "GPU (K3 0.521 against 0.501 ms, K2 0.164 against 0.151 ms): off by default")
     ap.add_argument("--tune", action="append", default=[], help="key=value for nsk_set_tuning (experiments), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of each CPU baseline's timed sample")
     args = ap.parse_args()
     TUNE[:] = args.tune
+    global PIPELINE
+    PIPELINE = args.pipeline
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

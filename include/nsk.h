@@ -234,6 +234,15 @@ int nsk_camera_backward(nsk_ctx* ctx, const float* d_cam, const float* d_g_c2w, 
 /* inside-bbox pre-filter (src/Mapper.cpp:416-427, src/Tracker.cpp:48-58): d_keep[n] = (t >= gt_depth) */
 int nsk_inside_filter(nsk_ctx* ctx, int N, const float* d_rays_o, const float* d_rays_d, const float* d_gt_depth,
                       uint8_t* d_keep);
+/* Sampling (+ cell sort) of the NEXT batch on a side stream.  It starts when what is enqueued on the context's stream at the time of the
+ * call has finished and runs beside what the caller enqueues afterwards (the gradient exchange, nsk_adam_step): call it right after the
+ * nsk_map_step of the current batch with the arguments the next nsk_map_step will get (same device pointers, same gt_depth_max, same
+ * flags, the same ray mask installed).  That nsk_map_step then finds its samples prepared and skips its own sampling launches; any
+ * other call simply samples as usual (a prepared set that is never asked for is dropped).  The rays must not depend on the running
+ * step's result (bundle adjustment moves poses: do not prepare then).  Results are those of the unprepared step. */
+int nsk_map_prepare(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d, const float* d_gt_depth, float gt_depth_max,
+                    unsigned flags);
+
 /* The reference drops the rays that fail the test above before it renders them (boolean-index compaction, src/Mapper.cpp:423-427,
  * src/Tracker.cpp:55-58), which needs their count on the host.  Here they stay in place and are neutralised instead: with a mask
  * installed (d_keep [N] as written by nsk_inside_filter, device memory, must stay valid; NULL = none), nsk_map_step, nsk_track_step and

@@ -688,6 +688,10 @@ struct Workspace {
     // cell sort of the samples (k_sample keys -> k_sort_scan -> k_sort_place): perm lists the samples cell by cell
     int* perm = nullptr; int* skey = nullptr; int* srank = nullptr;     // [capM]
     int* hist = nullptr; int* offs = nullptr; size_t hist_cap = 0;       // [bins of the key level]; hist is zero between steps
+    // second set of the sampling outputs: nsk_map_prepare fills it on the side stream while the current step runs; a step that finds its
+    // batch prepared swaps the pointers above with these
+    float* z_alt = nullptr; int* perm_alt = nullptr; int* skey_alt = nullptr; int* srank_alt = nullptr; int* offs_alt = nullptr;
+    int alt_capM = 0; size_t alt_bins = 0;
 };
 struct nsk_ctx {
     int device = 0;
@@ -726,6 +730,12 @@ struct nsk_ctx {
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
     bool sorted = false;                    // the current step's decoder launches walk the samples in cell-sorted order (ws.perm)
+    // nsk_map_prepare: the sampling (+ cell sort) of the NEXT batch on a side stream, concurrent with the current step
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_prep_done = nullptr, ev_alt_free = nullptr;
+    bool prep_outstanding = false;
+    struct Prep { bool valid = false; int stage = 0, N = 0, S = 0; const float* ro = nullptr; const float* rd = nullptr; const float* gt = nullptr;
+                  float gtmax = 0.f; const uint8_t* mask = nullptr; bool sorted = false; } prep;
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
     int matmul_mode = 1;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split (fp32-accurate, nsk_bf16.h)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
@@ -754,8 +764,9 @@ static bool roctx_ready()
 
 struct ProfScope {      // records start/stop events around the launches issued while it is alive
     nsk_ctx* c; hipEvent_t a = nullptr, b = nullptr; const char* name; bool ranged = false;
-    ProfScope(nsk_ctx* c_, const char* n) : c(c_), name(n)
+    ProfScope(nsk_ctx* c_, const char* n, bool on = true) : c(c_), name(n)
     {
+        if (!on) return;                                    // launches on the side stream are not timed (the events sit on c->stream)
         if (c->roctx && roctx_ready()) { g_roctx_push(n); ranged = true; }
         if (!c->prof) return;
         hipEventCreate(&a); hipEventCreate(&b);
@@ -848,6 +859,7 @@ static void free_ws(Workspace& w)
     for (int i = 0; i < 4; ++i) { hipFree(w.hsave[i]); w.hsave[i] = nullptr; w.hcap[i] = 0; w.hsave_M[i] = 0; }
     hipFree(w.g_raw); hipFree(w.ray_loss); hipFree(w.tmp_rgb); hipFree(w.tmp_depth); hipFree(w.tmp_var); hipFree(w.dec_slabs);
     hipFree(w.perm); hipFree(w.skey); hipFree(w.srank); if (w.hist) hipFree(w.hist - 16); hipFree(w.offs);
+    hipFree(w.z_alt); hipFree(w.perm_alt); hipFree(w.skey_alt); hipFree(w.srank_alt); hipFree(w.offs_alt);
     w = Workspace();
 }
 
@@ -863,6 +875,7 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
         hipFree(c->dec[i].fimg16); hipFree(c->dec[i].fidx16);
     }
     hipFree(c->xbuf); hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal); hipFree(c->fr_tmp);
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); hipEventDestroy(c->ev_prep_done); hipEventDestroy(c->ev_alt_free); }
     free_ws(c->ws);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1245,6 +1258,8 @@ static int ensure_ws(nsk_ctx* c, int N, int M)
     if (M <= w.capM && N <= w.capN) return 0;
     if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));
+    c->prep.valid = false; c->prep_outstanding = false;
     invalidate_graphs(c);
     int capM = std::max(M, w.capM), capN = std::max(N, w.capN);
     free_ws(w);
@@ -1271,6 +1286,8 @@ static int ensure_hist(nsk_ctx* c, size_t bins)
     if (bins <= w.hist_cap) return 0;
     if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));
+    c->prep.valid = false; c->prep_outstanding = false;
     invalidate_graphs(c);
     if (w.hist) hipFree(w.hist - 16);
     hipFree(w.offs);
@@ -1557,35 +1574,64 @@ static bool sort_pays(nsk_ctx* c, int stage, int M, unsigned flags)
 }
 
 // sorted: the decoders of this step (forward and the backward that follows) walk the samples cell by cell (see k_sample)
-static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax, bool save_masks,
-                        bool sorted = false)
+// sampling (+ cell sort) of one batch into the given output set, on the given stream
+static int launch_sampling(nsk_ctx* c, hipStream_t st, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax,
+                           const uint8_t* mask, bool sorted, float* z, int* skey, int* srank, int* offs, int* perm, float* gmax_slot, bool prof)
 {
     const int M = N * S;
-    const uint8_t* mask = save_masks ? c->ray_mask : nullptr;      // (only the steps that form a loss honour it; a plain render shows every ray)
-    c->sorted = sorted;
     int key_level = 0;
     for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) key_level = STAGE_DEC[stage][q];      // the finest level the stage reads
     const GridState& KG = c->grid[key_level];
     const GridState* PG = stage >= 2 ? &c->grid[1] : nullptr;      // parent level whose cells order the samples inside a key cell (k_sample)
     const size_t bins = KG.n / 32 * 8;
-    if (sorted) CHK(ensure_hist(c, bins));
     const float* gmax_dev = nullptr;
     if (gt && gtmax < 0.f && N > 8192) {        // smaller batches: k_sample's waves take the maximum themselves
-        ProfScope ps(c, "depth_max");
-        k_depth_max<<<1, 1024, 0, c->stream>>>(N, gt, mask, c->scal);
-        gmax_dev = c->scal;
+        ProfScope ps(c, "depth_max", prof);
+        k_depth_max<<<1, 1024, 0, st>>>(N, gt, mask, gmax_slot);
+        gmax_dev = gmax_slot;
     }
     {
-    ProfScope ps(c, "sample");
-    k_sample<<<(N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS, 64 * NSK_SAMPLE_RAYS, 0, c->stream>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, mask, c->ws.z, KG.X, KG.Y, KG.Z, PG ? PG->X : 0, PG ? PG->Y : 0, PG ? PG->Z : 0, (int)((bins / 8 + 1) / 2),
-                                                 sorted ? c->ws.skey : nullptr, c->ws.srank, c->ws.hist);
+    ProfScope ps(c, "sample", prof);
+    k_sample<<<(N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS, 64 * NSK_SAMPLE_RAYS, 0, st>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, mask, z, KG.X, KG.Y, KG.Z, PG ? PG->X : 0, PG ? PG->Y : 0, PG ? PG->Z : 0, (int)((bins / 8 + 1) / 2),
+                                                 sorted ? skey : nullptr, srank, c->ws.hist);
     }
     if (sorted) {
-        ProfScope ps(c, "cell_sort");
-        k_sort_scan<<<(int)((bins + 2047) / 2048), 256, 0, c->stream>>>((int)bins, (int)((bins / 8 + 1) / 2), c->ws.hist, c->ws.offs);
-        k_sort_place<<<(M + 255) / 256, 256, 0, c->stream>>>(M, c->ws.skey, c->ws.srank, c->ws.offs, c->ws.perm);
+        ProfScope ps(c, "cell_sort", prof);
+        k_sort_scan<<<(int)((bins + 2047) / 2048), 256, 0, st>>>((int)bins, (int)((bins / 8 + 1) / 2), c->ws.hist, offs);
+        k_sort_place<<<(M + 255) / 256, 256, 0, st>>>(M, skey, srank, offs, perm);
     }
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static size_t stage_bins(nsk_ctx* c, int stage)
+{
+    int key_level = 0;
+    for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) key_level = STAGE_DEC[stage][q];
+    return c->grid[key_level].n / 32 * 8;
+}
+
+static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax, bool save_masks,
+                        bool sorted = false)
+{
+    const int M = N * S;
+    const uint8_t* mask = save_masks ? c->ray_mask : nullptr;      // (only the steps that form a loss honour it; a plain render shows every ray)
+    nsk_ctx::Prep& P = c->prep;
+    if (P.valid && save_masks && !c->capturing && P.stage == stage && P.N == N && P.S == S && P.ro == ro && P.rd == rd && P.gt == gt && P.gtmax == gtmax &&
+        P.mask == mask && P.sorted == sorted) {
+        // this batch was sampled by nsk_map_prepare: take its outputs
+        Workspace& w = c->ws;
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_prep_done, 0));
+        std::swap(w.z, w.z_alt); std::swap(w.perm, w.perm_alt); std::swap(w.skey, w.skey_alt); std::swap(w.srank, w.srank_alt);
+        std::swap(w.offs, w.offs_alt);                      // (both sets are kept at the same capacities: ensure_alt)
+        P.valid = false; c->prep_outstanding = false;
+        c->sorted = sorted;
+    } else {
+        if (c->prep_outstanding) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_prep_done, 0));      // the cell histogram is shared with the side stream
+        c->sorted = sorted;
+        if (sorted) CHK(ensure_hist(c, stage_bins(c, stage)));
+        CHK(launch_sampling(c, c->stream, stage, N, S, ro, rd, gt, gtmax, mask, sorted, c->ws.z, c->ws.skey, c->ws.srank, c->ws.offs, c->ws.perm, c->scal, true));
+    }
     CHK(launch_decode_fwd_stage(c, stage, M, S, ro, rd, save_masks));
     return 0;
 }
@@ -1761,6 +1807,55 @@ extern "C" int nsk_render_backward(nsk_ctx* c, int stage, int N, const float* ro
     HIPCHK(hipGetLastError());
     CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd));
     account(c, stage, N * S, N, true, flags);
+    return 0;
+}
+
+// second set of sampling outputs, kept at the capacities of the first
+static int ensure_alt(nsk_ctx* c, bool need_offs)
+{
+    Workspace& w = c->ws;
+    if (w.alt_capM < w.capM) {
+        HIPCHK(hipStreamSynchronize(c->stream2));
+        hipFree(w.z_alt); hipFree(w.perm_alt); hipFree(w.skey_alt); hipFree(w.srank_alt);
+        const size_t m = (size_t)w.capM + 64;
+        HIPCHK(hipMalloc(&w.z_alt, m * 4)); HIPCHK(hipMalloc(&w.perm_alt, m * 4)); HIPCHK(hipMalloc(&w.skey_alt, m * 4)); HIPCHK(hipMalloc(&w.srank_alt, m * 4));
+        w.alt_capM = w.capM;
+    }
+    if (need_offs && w.alt_bins < w.hist_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream2));
+        hipFree(w.offs_alt);
+        HIPCHK(hipMalloc(&w.offs_alt, w.hist_cap * 4));
+        w.alt_bins = w.hist_cap;
+    }
+    return 0;
+}
+
+extern "C" int nsk_map_prepare(nsk_ctx* c, int stage, int N, const float* ro, const float* rd, const float* gt, float gtmax, unsigned flags)
+{
+    int S;
+    if (!gt) return fail("nsk_map_prepare: gt_depth is NULL");
+    if (c && c->capturing) return fail("nsk_map_prepare: not inside a graph capture");
+    CHK(common_checks(c, stage, N, ro, rd, &S, gt));
+    if (!c->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_prep_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_alt_free, hipEventDisableTiming));
+    }
+    const bool sorted = sort_pays(c, stage, N * S, flags);
+    if (sorted) CHK(ensure_hist(c, stage_bins(c, stage)));
+    CHK(ensure_alt(c, sorted));
+    // The side stream starts when everything enqueued on the main stream SO FAR has finished -- the step just issued, i.e. it runs beside
+    // whatever the caller enqueues next (the gradient exchange, the optimiser step).  Sampling beside the step's own decoder launches
+    // was measured and lost: the GPU is full, the forward slowed by what the sampling took and the cross-stream waits came on top
+    // (K3 0.511 against 0.500 ms, K2 0.163 against 0.151 ms).  This one wait also covers both hazards: the set being overwritten
+    // (last read by earlier steps) and the cell histogram (shared with the main stream's own sampling).
+    HIPCHK(hipEventRecord(c->ev_alt_free, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_alt_free, 0));
+    Workspace& w = c->ws;
+    CHK(launch_sampling(c, c->stream2, stage, N, S, ro, rd, gt, gtmax, c->ray_mask, sorted, w.z_alt, w.skey_alt, w.srank_alt, w.offs_alt, w.perm_alt, c->scal + 12, false));
+    HIPCHK(hipEventRecord(c->ev_prep_done, c->stream2));
+    c->prep_outstanding = true;
+    nsk_ctx::Prep& P = c->prep;
+    P.valid = true; P.stage = stage; P.N = N; P.S = S; P.ro = ro; P.rd = rd; P.gt = gt; P.gtmax = gtmax; P.mask = c->ray_mask; P.sorted = sorted;
     return 0;
 }
 

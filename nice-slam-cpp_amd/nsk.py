@@ -22,7 +22,7 @@ SYMBOLS = (
     "nsk_decoder_set_trainable", "nsk_render_forward", "nsk_eval_points", "nsk_raw2outputs", "nsk_render_backward", "nsk_map_step",
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
     "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
-    "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_prepare_rays", "nsk_grad_slab", "nsk_grad_pack", "nsk_grad_unpack", "nsk_allreduce_grads", "nsk_last_call_stats",
+    "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_prepare_rays", "nsk_map_prepare", "nsk_grad_slab", "nsk_grad_pack", "nsk_grad_unpack", "nsk_allreduce_grads", "nsk_last_call_stats",
     "nsk_profile_begin", "nsk_profile_end",
 )
 
@@ -341,6 +341,11 @@ class Context:
         _chk(lib().nsk_map_step(self.h, _stage(stage), N, _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), _ptr(gt_color),
                                 C.c_float(gt_depth_max), C.c_float(w_color), int(use_color), C.c_uint(flags), _ptr(loss),
                                 _ptr(rgb), _ptr(depth), _ptr(var), _ptr(g_ro), _ptr(g_rd)))
+
+    @_ordered
+    def map_prepare(self, stage, rays_o, rays_d, gt_depth, gt_depth_max=-1.0, flags=GRAD_GRIDS | GRAD_DECODERS):
+        """nsk_map_prepare: sample (and cell-sort) the NEXT batch on the context's side stream while the current step runs"""
+        _chk(lib().nsk_map_prepare(self.h, _stage(stage), rays_o.shape[0], _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), C.c_float(gt_depth_max), C.c_uint(flags)))
 
     @_ordered
     def track_step(self, stage, rays_o, rays_d, gt_depth, gt_color, gt_depth_max=-1.0, w_color=0.5, use_color=True,

@@ -186,3 +186,40 @@ def test_deterministic_debug_mode_is_bit_reproducible():
         assert np.abs(out["det_a"][0][k]).max() > 0 and rel_l2(out["det_a"][0][k], out["normal"][0][k]) < 1e-5, k
     assert np.array_equal(out["det_a"][1], out["det_b"][1]) and rel_l2(out["det_a"][1], out["normal"][1]) < 1e-5
     assert out["det_a"][2] == out["det_b"][2]
+
+
+def test_map_prepare_gives_the_unprepared_steps():
+    """nsk_map_prepare (sampling + cell sort of the next batch on the side stream): four mapping steps over two alternating batches with
+    every next batch prepared, against the same steps without it -- same losses and parameters up to the order of the gradient sums,
+    and the prepared steps really skip their own sampling launches"""
+    sc = scenes.make_scene(11, grid_std=0.05)
+    batches = []
+    for k in range(2):
+        r = scenes.make_rays(50 + k, 400, sc["bound"], n_frames=5)
+        batches.append([cu(r[x]) for x in ("rays_o", "rays_d", "gt_depth", "gt_color")] + [float(r["gt_depth"].max())])
+    out = []
+    for prepare in (False, True):
+        ctx = make_ctx(sc, trainable=["color"])
+        ctx.set_sort_mode(1)
+        loss = torch.zeros(1, device="cuda")
+        losses, names = [], None
+        with torch.cuda.stream(ctx.tstream):
+            for i in range(4):
+                ro, rd, gd, gc, gm = batches[i % 2]
+                if i == 2:
+                    ctx.profile_begin()
+                ctx.map_step("color", ro, rd, gd, gc, gm, 0.2, True, flags=3, loss=loss)
+                if prepare:
+                    n = batches[(i + 1) % 2]
+                    ctx.map_prepare("color", n[0], n[1], n[2], n[4], flags=3)
+                ctx.adam_step(LR)
+                losses.append(float(loss))
+            names = set(ctx.profile_end().keys())
+        out.append((losses, {k: ctx.grid_download(k) for k in ("middle", "fine", "color")}, ctx.decoder_download("color"), names))
+        ctx.close()
+    (l0, g0, d0, n0), (l1, g1, d1, n1) = out
+    assert "sample" in n0 and "cell_sort" in n0 and "sample" not in n1 and "cell_sort" not in n1
+    assert np.allclose(l0, l1, rtol=1e-5)
+    for k in g0:
+        assert rel_l2(g1[k] - sc["grids"][k], g0[k] - sc["grids"][k]) < 5e-3, k          # (Adam amplifies last-bit differences of the sums: see test_gpu_configs)
+    assert rel_l2(d1, d0) < 1e-4

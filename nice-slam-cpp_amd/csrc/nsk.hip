@@ -58,7 +58,7 @@ __global__ void k_adam(int n, float* __restrict__ p, float* __restrict__ g, floa
 
 struct AdamSeg { float* p; float* g; float* m; float* v; const int* idx; int nidx; int n; float step_size, bc2s; int blk_end;      // idx: the marked voxels (nullptr = all)
                  const int* inv_f; const int* inv_b; float* fimg; float* bimg;      // decoders: image position of each parameter (-1 none)
-                 const int* inv16; unsigned short* img16; float* img16_tail; int tail_off;
+                 const int* inv16; unsigned short* img16; float* img16_tail; int tail_off; int np16;
                  const float* slabs; int nslabs, slab_stride; };                      // pending per-workgroup gradient slabs (k_decode_bwd_multi)   // bf16 3-piece image (nsk_bf16.h), its fp32 tail
 struct AdamArgs { AdamSeg s[8]; int n; float b1, b2, eps; };
 // all parameter groups of one optimiser step in one launch (3 grid levels + trainable decoders)
@@ -117,17 +117,7 @@ __global__ void k_adam_multi(AdamArgs A)
             if (bi >= 0) S.bimg[bi] = pp[k];
             if (S.inv16) {
                 const int t = S.inv16[4 * i + k];
-                if (t >= 0) {            // same split as k_pack_bf16
-                    const float x = pp[k];
-                    const __bf16 h = (__bf16)x;
-                    const float r1 = x - (float)h;
-                    const __bf16 m = (__bf16)r1;
-                    const __bf16 l = (__bf16)(r1 - (float)m);
-                    const size_t base = ((size_t)(t >> 9) * 3 * 64 + ((t >> 3) & 63)) * 8 + (t & 7);
-                    S.img16[base] = __builtin_bit_cast(unsigned short, h);
-                    S.img16[base + 64 * 8] = __builtin_bit_cast(unsigned short, m);
-                    S.img16[base + 128 * 8] = __builtin_bit_cast(unsigned short, l);
-                }
+                if (t >= 0) store_pieces(S.img16, t, pp[k], S.np16);
                 if (fi >= S.tail_off) S.img16_tail[fi - S.tail_off] = pp[k];
             }
         }
@@ -669,7 +659,7 @@ struct DecState {
     int* finv = nullptr; int* binv = nullptr;     // inverse of fidx / bidx: image position of each canonical parameter
     int* inv16 = nullptr;                         // inverse of fidx16
     float* bimg16 = nullptr; int* bidx16 = nullptr; int bfrag16_n = 0; bool bimg16_dirty = true;   // bf16 3-piece backward image (frozen chain), repacked lazily
-    float* fimg16 = nullptr; int* fidx16 = nullptr; int frag16_n = 0, fimg16_f = 0, tail_off = 0, tail16_off = 0;   // bf16 3-piece forward image
+    float* fimg16 = nullptr; int* fidx16 = nullptr; int frag16_n = 0, fimg16_f = 0, tail_off = 0, tail16_off = 0, np16 = 3, cq16 = 2;   // forward image in pieces: 3 bf16 (mode 1) or 2 fp16 (mode 2)
     int fimg_n = 0, bimg_n = 0;
     int trainable = 0;
     bool loaded = false;
@@ -737,7 +727,7 @@ struct nsk_ctx {
     struct Prep { bool valid = false; int stage = 0, N = 0, S = 0; const float* ro = nullptr; const float* rd = nullptr; const float* gt = nullptr;
                   float gtmax = 0.f; const uint8_t* mask = nullptr; bool sorted = false; } prep;
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
-    int matmul_mode = 1;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split (fp32-accurate, nsk_bf16.h)
+    int matmul_mode = 2;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split, 2 fp16 2-piece split (nsk_bf16.h)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
     // optional per-kernel timing with HIP events on the context's stream (nsk_profile_begin / _end)
     bool prof = false;
@@ -846,7 +836,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     SETB(0) SETB(1) SETB(2) SETB(3)
 #undef SETB
     CHK(set_lds(k_median_thr, 16384 * 4));
-    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024));
+    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8, 2>, 160 * 1024));
     CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
     *out = c;
     return 0;
@@ -885,11 +875,19 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
 extern "C" int nsk_sync(nsk_ctx* c) { if (!c) return fail("null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
 extern "C" void* nsk_stream(nsk_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+static int repack16(nsk_ctx* c, int w);
 extern "C" int nsk_set_matmul_mode(nsk_ctx* c, int mode)
 {
     if (!c) return fail("null ctx");
-    if (mode != 0 && mode != 1) return fail("nsk_set_matmul_mode: mode must be 0 (fp32 MFMA) or 1 (bf16 3-piece split)");
+    if (mode < 0 || mode > 2) return fail("nsk_set_matmul_mode: mode must be 0 (fp32 MFMA), 1 (bf16 3-piece split) or 2 (fp16 2-piece split)");
+    if (c->capturing) return fail("nsk_set_matmul_mode: not while a graph is being captured");
+    const bool relayout = (mode == 2) != (c->matmul_mode == 2);
     c->matmul_mode = mode;
+    if (relayout) {              // the forward images change their piece format: rebuild those of the loaded decoders
+        HIPCHK(hipSetDevice(c->device));
+        for (int w = 1; w < 4; ++w) if (c->dec[w].loaded && c->dec[w].fimg16) CHK(repack16(c, w));
+        invalidate_graphs(c);
+    }
     return 0;
 }
 
@@ -1140,11 +1138,20 @@ static int ensure_bimg16(nsk_ctx* c, int w)
     return 0;
 }
 
+// the forward image holds 3 bf16 pieces (matmul modes 0 / 1) or 2 fp16 pieces (mode 2) per weight; the fp32 tail follows the fragments
+static void set_np16(DecState& D, int np)
+{
+    D.np16 = np;
+    if (D.cq16 == 4) { D.fimg16_f = np == 2 ? MlpFwdImgB<4, 2>::TOTAL_F : MlpFwdImgB<4, 3>::TOTAL_F; D.tail16_off = np == 2 ? MlpFwdImgB<4, 2>::P_F32 : MlpFwdImgB<4, 3>::P_F32; }
+    else { D.fimg16_f = np == 2 ? MlpFwdImgB<2, 2>::TOTAL_F : MlpFwdImgB<2, 3>::TOTAL_F; D.tail16_off = np == 2 ? MlpFwdImgB<2, 2>::P_F32 : MlpFwdImgB<2, 3>::P_F32; }
+}
+
 static int repack16(nsk_ctx* c, int w)
 {
     DecState& D = c->dec[w];
     if (!D.fimg16) return 0;
-    k_pack_bf16<<<(D.frag16_n + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<unsigned short*>(D.fimg16), D.fidx16, D.p, D.frag16_n);
+    set_np16(D, c->matmul_mode == 2 ? 2 : 3);
+    k_pack_bf16<<<(D.frag16_n + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<unsigned short*>(D.fimg16), D.fidx16, D.p, D.frag16_n, D.np16);
     k_pack<<<(740 + 255) / 256, 256, 0, c->stream>>>(D.fimg16 + D.tail16_off, D.fidx + D.tail_off, D.p, 740);     // fp32 tail: biases, Wo, bo, B
     HIPCHK(hipGetLastError());
     return 0;
@@ -1188,8 +1195,9 @@ extern "C" int nsk_decoder_upload(nsk_ctx* c, int w, const float* h, size_t n)
         HIPCHK(hipMemcpy(D.bidx, bi.data(), bi.size() * 4, hipMemcpyHostToDevice));
         if (w != 0) {
             std::vector<int> i16;
-            if (w == 2) { build_idx16<4>(nsk_dec_layout(w), i16); D.fimg16_f = MlpFwdImgB<4>::TOTAL_F; D.tail16_off = MlpFwdImgB<4>::P_F32; D.tail_off = MlpFwdImg<4>::P_B; }
-            else { build_idx16<2>(nsk_dec_layout(w), i16); D.fimg16_f = MlpFwdImgB<2>::TOTAL_F; D.tail16_off = MlpFwdImgB<2>::P_F32; D.tail_off = MlpFwdImg<2>::P_B; }
+            if (w == 2) { build_idx16<4>(nsk_dec_layout(w), i16); D.cq16 = 4; D.tail_off = MlpFwdImg<4>::P_B; }
+            else { build_idx16<2>(nsk_dec_layout(w), i16); D.cq16 = 2; D.tail_off = MlpFwdImg<2>::P_B; }
+            set_np16(D, 3);          // allocate for the larger (3-piece) form
             D.frag16_n = (int)i16.size();
             HIPCHK(hipMalloc(&D.fimg16, (size_t)D.fimg16_f * 4)); HIPCHK(hipMalloc(&D.fidx16, i16.size() * 4));
             HIPCHK(hipMemset(D.fimg16, 0, (size_t)D.fimg16_f * 4));
@@ -1532,10 +1540,11 @@ static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const fl
     MA.n = n;
     split_wgs_balanced(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end, 8);
     ProfScope ps(c, "decode_fwd_multi");
-    if (c->matmul_mode == 1) {
+    if (c->matmul_mode != 0) {
         size_t lds16 = 0;
         for (int r = 0; r < n; ++r) lds16 = std::max(lds16, MA.which[r] == 0 ? fwd_img_floats(0) * 4 : (size_t)c->dec[MA.which[r]].fimg16_f * 4);
-        k_decode_fwd_multi_bf16<8><<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);       // 12 waves (168 VGPRs) spill: 59 -> 71 us
+        if (c->matmul_mode == 2) k_decode_fwd_multi_bf16<8, 2><<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);
+        else k_decode_fwd_multi_bf16<8><<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);       // 12 waves (168 VGPRs) spill: 59 -> 71 us
     } else
     k_decode_fwd_multi<<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
     HIPCHK(hipGetLastError());
@@ -2228,7 +2237,7 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
                 S.slabs = c->ws.dec_slabs; S.nslabs = c->pend_nb; S.slab_stride = n4; c->pend_w = -1;
                 blocks += (n4 / 4 + 7) / 8 - (n4 / 4 + 255) / 256;         // 8 float4 per block (see k_adam_multi)
             }
-            if (D.fimg16) { S.inv16 = D.inv16; S.img16 = reinterpret_cast<unsigned short*>(D.fimg16); S.img16_tail = D.fimg16 + D.tail16_off; S.tail_off = D.tail_off; }
+            if (D.fimg16) { S.inv16 = D.inv16; S.img16 = reinterpret_cast<unsigned short*>(D.fimg16); S.img16_tail = D.fimg16 + D.tail16_off; S.tail_off = D.tail_off; S.np16 = D.np16; }
             blocks += (n4 / 4 + 255) / 256; S.blk_end = blocks;
         }
         c->touched[NSK_GROUP_DECODERS] = false;

@@ -16,7 +16,7 @@
 #pragma once
 #include "nsk_device.h"
 
-template <int CQ>
+template <int CQ, int NP = 3>                     // NP pieces per weight: 3 = bf16 split (mode 1), 2 = fp16 split (mode 2)
 struct MlpFwdImgB {                               // block (K=32) indices of the segments; fragment group = 2*blk + rt
     static constexpr int CB = CQ / 2;
     static constexpr int W0E = 0;                 // 3 blocks
@@ -31,7 +31,7 @@ struct MlpFwdImgB {                               // block (K=32) indices of the
     static constexpr int W4 = F3 + CB;
     static constexpr int F4 = W4 + 1;
     static constexpr int NBLK = F4 + CB;          // 15 (CQ=2), 20 (CQ=4)
-    static constexpr int FRAG_BYTES = NBLK * 2 * 3 * 1024;
+    static constexpr int FRAG_BYTES = NBLK * 2 * NP * 1024;
     static constexpr int P_F32 = FRAG_BYTES / 4;  // float offset of the plain fp32 tail (same order as MlpFwdImg)
     static constexpr int P_B = P_F32;
     static constexpr int P_BC = P_B + 160;
@@ -45,22 +45,34 @@ struct MlpFwdImgB {                               // block (K=32) indices of the
 
 __host__ __device__ inline int nsk_bf16_kperm(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); }
 
-// image build: one thread per (fragment group, lane, j); idx = canonical parameter offset or -1
-__global__ void k_pack_bf16(unsigned short* __restrict__ img, const int* __restrict__ idx, const float* __restrict__ P, int n)
+// the pieces of one weight: np = 3 -> bf16 h, m, l; np = 2 -> fp16 h and the 2048-fold low piece
+__device__ __forceinline__ void store_pieces(unsigned short* __restrict__ img, int t, float x, int np)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
     const int fg = t >> 9, lane = (t >> 3) & 63, j = t & 7;
-    const int k = idx[t];
-    const float x = k >= 0 ? P[k] : 0.f;
+    const size_t base = ((size_t)fg * np * 64 + lane) * 8 + j;
+    if (np == 2) {
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)((x - (float)h) * NSK_H16_SCALE);
+        img[base] = __builtin_bit_cast(unsigned short, h);
+        img[base + 64 * 8] = __builtin_bit_cast(unsigned short, l);
+        return;
+    }
     const __bf16 h = (__bf16)x;
     const float r1 = x - (float)h;
     const __bf16 m = (__bf16)r1;
     const __bf16 l = (__bf16)(r1 - (float)m);
-    const size_t base = ((size_t)fg * 3 * 64 + lane) * 8 + j;
     img[base] = __builtin_bit_cast(unsigned short, h);
     img[base + 64 * 8] = __builtin_bit_cast(unsigned short, m);
     img[base + 128 * 8] = __builtin_bit_cast(unsigned short, l);
+}
+
+// image build: one thread per (fragment group, lane, j); idx = canonical parameter offset or -1
+__global__ void k_pack_bf16(unsigned short* __restrict__ img, const int* __restrict__ idx, const float* __restrict__ P, int n, int np = 3)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int k = idx[t];
+    store_pieces(img, t, k >= 0 ? P[k] : 0.f, np);
 }
 
 // static schedule (see FwdSched): step s multiplies weight block blk[s] with input block xs[s]
@@ -118,13 +130,53 @@ __device__ __forceinline__ void mlp_forward_bf16(const bf8* __restrict__ img, co
     A.mask = mask;
 }
 
+// the same chain on fp16 pieces (matmul mode 2): three MFMAs per K=32 block and row tile instead of six, two accumulator sets
+// (accH: Wh x_h from the bias on; accL: the two cross products, in units of 1/2048) that meet before every ReLU and block output
+template <int CQ>
+__device__ __forceinline__ void mlp_forward_f16(const h8* __restrict__ img, const float* __restrict__ imgf, int lane, Act<CQ>& A)
+{
+    typedef MlpFwdImgB<CQ, 2> I;
+    constexpr FwdSchedB<CQ> S{};
+    const int g = lane >> 4;
+    constexpr float INV = 1.f / NSK_H16_SCALE;
+    H2 X[S.XH + 1];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) X[S.XE + b] = split_block_h(A.xe[2 * b], A.xe[2 * b + 1]);
+#pragma unroll
+    for (int b = 0; b < S.CB; ++b) X[S.XC + b] = split_block_h(A.xc[2 * b], A.xc[2 * b + 1]);
+    FragH ring[2][2];
+    ring[0][0] = load_frag_h(img, 2 * S.blk[0], lane); ring[0][1] = load_frag_h(img, 2 * S.blk[0] + 1, lane);
+    unsigned long long mask = 0;
+    f4 acc[2], accL[2] = {(f4)(0.f), (f4)(0.f)};
+    load_bias(imgf + I::P_B, g, acc);
+#pragma unroll
+    for (int s = 0; s < S.NSTEP; ++s) {
+        if (s + 1 < S.NSTEP) { ring[(s + 1) & 1][0] = load_frag_h(img, 2 * S.blk[s + 1], lane); ring[(s + 1) & 1][1] = load_frag_h(img, 2 * S.blk[s + 1] + 1, lane); }
+        __builtin_amdgcn_sched_barrier(0);
+        mac_block_h(ring[s & 1][0], ring[s & 1][1], X[S.xs[s]], acc, accL);
+        if (S.bnd[s] != 0) {
+            acc[0] += accL[0] * INV; acc[1] += accL[1] * INV;
+            accL[0] = (f4)(0.f); accL[1] = (f4)(0.f);
+        }
+        if (S.bnd[s] == 1) {
+            mask |= (unsigned long long)relu_mask(acc) << (8 * S.lay[s]);
+            f4 bc[2]; load_bias(imgf + I::P_BC + 32 * S.lay[s], g, bc); acc[0] += bc[0]; acc[1] += bc[1];
+        } else if (S.bnd[s] == 2) {
+            const int l = S.lay[s];
+            A.h[l][0] = acc[0]; A.h[l][1] = acc[1];
+            if (l < 4) { X[S.XH] = split_block_h(acc[0], acc[1]); load_bias(imgf + I::P_B + 32 * (l + 1), g, acc); }
+        }
+    }
+    A.mask = mask;
+}
+
 // K2 (bf16-split form): same contract as decode_fwd_body for the MLP decoders (WHICH = 1, 2, 3)
-template <int WHICH, int NW = 8>
+template <int WHICH, int NW = 8, int NP = 3>
 __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, int nb)
 {
     constexpr int CQ = WHICH == 2 ? 4 : 2;
     constexpr int OD = WHICH == 3 ? 4 : 1;
-    typedef MlpFwdImgB<CQ> I;
+    typedef MlpFwdImgB<CQ, NP> I;
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const f4* src = reinterpret_cast<const f4*>(A.img16);
     copy_image_to_lds<64 * NW>(smem, src, I::TOTAL_F / 4);
@@ -169,7 +221,8 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
             tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
             tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
         }
-        mlp_forward_bf16<CQ>(img, imgf, lane, C);
+        if constexpr (NP == 2) mlp_forward_f16<CQ>(reinterpret_cast<const h8*>(smem), imgf, lane, C);
+        else mlp_forward_bf16<CQ>(img, imgf, lane, C);
         float out[OD];
         mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);
         if (slot < A.M) {
@@ -183,7 +236,7 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
     }
 }
 
-template <int NW>
+template <int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW) void k_decode_fwd_multi_bf16(MultiArgs MA)
 {
     int r = 0;
@@ -192,8 +245,8 @@ __global__ __launch_bounds__(64 * NW) void k_decode_fwd_multi_bf16(MultiArgs MA)
     const int bid = blockIdx.x - b0, nb = MA.wg_end[r] - b0;
     switch (MA.which[r]) {
     case 0: decode_fwd_body<0, NW>(MA.a[r], bid, nb); break;
-    case 1: decode_fwd_bf16_body<1, NW>(MA.a[r], bid, nb); break;
-    case 2: decode_fwd_bf16_body<2, NW>(MA.a[r], bid, nb); break;
-    default: decode_fwd_bf16_body<3, NW>(MA.a[r], bid, nb); break;
+    case 1: decode_fwd_bf16_body<1, NW, NP>(MA.a[r], bid, nb); break;
+    case 2: decode_fwd_bf16_body<2, NW, NP>(MA.a[r], bid, nb); break;
+    default: decode_fwd_bf16_body<3, NW, NP>(MA.a[r], bid, nb); break;
     }
 }

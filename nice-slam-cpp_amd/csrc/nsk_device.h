@@ -430,6 +430,39 @@ __device__ __forceinline__ void mac_block(const Frag3& a0, const Frag3& a1, cons
     acc[0] = mfma_b(a0.m, x.m, acc[0]); acc[1] = mfma_b(a1.m, x.m, acc[1]);
 }
 
+// ---- fp16 2-piece split helpers (matmul mode 2; the scheme is described in nsk_bf16.h) ------------------
+// x = h + l / 2048 with h = fp16(x) (round to nearest even, v_cvt_pk_f16_f32) and l = fp16(2048 (x - h)): 22 significant bits.
+// The low pieces are kept scaled by 2^11 so that they never reach fp16's subnormal range before x itself does; the two
+// cross products therefore accumulate in their own registers (accL) and join the main sum with one fma per element.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define NSK_H16_SCALE 2048.f
+struct H2 { h8 h, l; };
+__device__ __forceinline__ H2 split_block_h(f4 q0, f4 q1)
+{
+    H2 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? q0[j] : q1[j - 4];
+        const _Float16 h = (_Float16)x;
+        r.h[j] = h; r.l[j] = (_Float16)((x - (float)h) * NSK_H16_SCALE);
+    }
+    return r;
+}
+struct FragH { h8 h, l; };
+__device__ __forceinline__ FragH load_frag_h(const h8* __restrict__ img, int fg, int lane)
+{
+    const h8* b = img + (size_t)fg * 2 * 64 + lane;
+    FragH f; f.h = b[0]; f.l = b[64];
+    return f;
+}
+__device__ __forceinline__ f4 mfma_h(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// accH[rt] += Wh x_h;  accL[rt] += Wh x_l + Wl x_h  (three fp16 products per output tile, two independent chains)
+__device__ __forceinline__ void mac_block_h(const FragH& a0, const FragH& a1, const H2& x, f4 (&accH)[2], f4 (&accL)[2])
+{
+    accH[0] = mfma_h(a0.h, x.h, accH[0]); accH[1] = mfma_h(a1.h, x.h, accH[1]);
+    accL[0] = mfma_h(a0.h, x.l, accL[0]); accL[1] = mfma_h(a1.h, x.l, accL[1]);
+    accL[0] = mfma_h(a0.l, x.h, accL[0]); accL[1] = mfma_h(a1.l, x.h, accL[1]);
+}
 
 // backward (transposed) image of an MLP decoder in bf16 pieces, for the frozen-decoder chain without ray gradients:
 // fragment group FT(l) + rt: fc[l]^T rows 16rt.. (grid features 0..31), WT(l) + rt: pts_linear[l]^T (h part), K = 32 each

@@ -59,6 +59,7 @@ __global__ void k_adam(int n, float* __restrict__ p, float* __restrict__ g, floa
 struct AdamSeg { float* p; float* g; float* m; float* v; const int* idx; int nidx; int n; float step_size, bc2s; int blk_end;      // idx: the marked voxels (nullptr = all)
                  const int* inv_f; const int* inv_b; float* fimg; float* bimg;      // decoders: image position of each parameter (-1 none)
                  const int* inv16; unsigned short* img16; float* img16_tail; int tail_off; int np16;
+                 const int* invh; unsigned short* imgh; float* imgh_tail; int btail_off;      // fp16 backward image (MlpBwdImgH) and its fp32 tail
                  const float* slabs; int nslabs, slab_stride; };                      // pending per-workgroup gradient slabs (k_decode_bwd_multi)   // bf16 3-piece image (nsk_bf16.h), its fp32 tail
 struct AdamArgs { AdamSeg s[8]; int n; float b1, b2, eps; };
 // all parameter groups of one optimiser step in one launch (3 grid levels + trainable decoders)
@@ -119,6 +120,11 @@ __global__ void k_adam_multi(AdamArgs A)
                 const int t = S.inv16[4 * i + k];
                 if (t >= 0) store_pieces(S.img16, t, pp[k], S.np16);
                 if (fi >= S.tail_off) S.img16_tail[fi - S.tail_off] = pp[k];
+            }
+            if (S.invh) {
+                const int t = S.invh[4 * i + k];
+                if (t >= 0) store_pieces(S.imgh, t, pp[k], 2);
+                if (bi >= S.btail_off) S.imgh_tail[bi - S.btail_off] = pp[k];
             }
         }
     }
@@ -658,6 +664,7 @@ struct DecState {
     int* fidx = nullptr; int* bidx = nullptr;
     int* finv = nullptr; int* binv = nullptr;     // inverse of fidx / bidx: image position of each canonical parameter
     int* inv16 = nullptr;                         // inverse of fidx16
+    int* invh = nullptr;                          // inverse of bidx16 (fp16 backward image)
     float* bimg16 = nullptr; int* bidx16 = nullptr; int bfrag16_n = 0; bool bimg16_dirty = true;   // bf16 3-piece backward image (frozen chain), repacked lazily
     float* fimg16 = nullptr; int* fidx16 = nullptr; int frag16_n = 0, fimg16_f = 0, tail_off = 0, tail16_off = 0, np16 = 3, cq16 = 2;   // forward image in pieces: 3 bf16 (mode 1) or 2 fp16 (mode 2)
     int fimg_n = 0, bimg_n = 0;
@@ -861,7 +868,7 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
     for (int i = 0; i < 4; ++i) {
         hipFree(c->grid[i].v); hipFree(c->grid[i].m); hipFree(c->grid[i].s); hipFree(c->grid[i].mask); hipFree(c->grid[i].midx);
         hipFree(c->dec[i].p); hipFree(c->dec[i].m); hipFree(c->dec[i].s); hipFree(c->dec[i].fimg); hipFree(c->dec[i].bimg);
-        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv); hipFree(c->dec[i].inv16); hipFree(c->dec[i].bimg16); hipFree(c->dec[i].bidx16);
+        hipFree(c->dec[i].fidx); hipFree(c->dec[i].bidx); hipFree(c->dec[i].finv); hipFree(c->dec[i].binv); hipFree(c->dec[i].inv16); hipFree(c->dec[i].invh); hipFree(c->dec[i].bimg16); hipFree(c->dec[i].bidx16);
         hipFree(c->dec[i].fimg16); hipFree(c->dec[i].fidx16);
     }
     hipFree(c->xbuf); hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal); hipFree(c->fr_tmp);
@@ -1114,25 +1121,29 @@ static void build_idx16(const DecLayout& L, std::vector<int>& idx)
 
 static void build_idx16b(const DecLayout& L, std::vector<int>& idx)
 {
-    idx.assign((size_t)MlpBwdImgB::NFG * 512, -1);
-    auto seg = [&](int fg0, int Wofs, int ld, int col0) {        // transposed: row o = input column, k = output row of the forward weight
-        for (int rt = 0; rt < 2; ++rt) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+    typedef MlpBwdImgH J;
+    idx.assign((size_t)J::NFG * 512, -1);
+    auto seg = [&](int fg0, int nrt, int Wofs, int ld, int col0, int rows) {   // transposed: row o = input column, k = output row of the forward weight
+        for (int rt = 0; rt < nrt; ++rt) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
             const int o = 16 * rt + (lane & 15), k = nsk_bf16_kperm(lane >> 4, j);
-            idx[((size_t)(fg0 + rt) * 64 + lane) * 8 + j] = Wofs + k * ld + col0 + o;
+            idx[((size_t)(fg0 + rt) * 64 + lane) * 8 + j] = o < rows ? Wofs + k * ld + col0 + o : -1;
         }
     };
-    for (int l = 0; l < 5; ++l) seg(MlpBwdImgB::FT(l), L.oFw[l], L.c_dim, 0);
-    for (int l = 1; l < 5; ++l) seg(MlpBwdImgB::WT(l), L.oW[l], L.in_dim[l], l == 3 ? NSK_E : 0);
+    for (int l = 0; l < 5; ++l) seg(J::FT(l), 2, L.oFw[l], L.c_dim, 0, 32);
+    for (int l = 1; l < 5; ++l) seg(J::WT(l), 2, L.oW[l], L.in_dim[l], l == 3 ? NSK_E : 0, 32);
+    seg(J::W0ET, 6, L.oW[0], NSK_E, 0, NSK_E);
+    seg(J::W3ET, 6, L.oW[3], 125, 0, NSK_E);
 }
 
-// the frozen chain's bf16 backward image follows the parameters lazily: marked stale by uploads and Adam steps, rebuilt before use
+// the fp16 backward image (MlpBwdImgH) follows the parameters lazily: marked stale by uploads and by Adam steps on a decoder whose image
+// the optimiser launch does not rewrite itself, rebuilt before use
 static int ensure_bimg16(nsk_ctx* c, int w)
 {
     DecState& D = c->dec[w];
     if (!D.bimg16 || !D.bimg16_dirty) return 0;
     ProfScope ps(c, "pack_bwd_bf16");
-    k_pack_bf16<<<(D.bfrag16_n + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<unsigned short*>(D.bimg16), D.bidx16, D.p, D.bfrag16_n);
-    k_pack<<<1, 128, 0, c->stream>>>(D.bimg16 + MlpBwdImgB::P_WO, D.bidx + MlpBwdImg::P_WO, D.p, 128);
+    k_pack_bf16<<<(D.bfrag16_n + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<unsigned short*>(D.bimg16), D.bidx16, D.p, D.bfrag16_n, 2);
+    k_pack<<<2, 256, 0, c->stream>>>(D.bimg16 + MlpBwdImgH::P_WO, D.bidx + MlpBwdImg::P_WO, D.p, 128 + 288);     // fp32 tail: Wo, B
     HIPCHK(hipGetLastError());
     D.bimg16_dirty = false;
     return 0;
@@ -1205,9 +1216,13 @@ extern "C" int nsk_decoder_upload(nsk_ctx* c, int w, const float* h, size_t n)
             std::vector<int> ib;
             build_idx16b(nsk_dec_layout(w), ib);
             D.bfrag16_n = (int)ib.size();
-            HIPCHK(hipMalloc(&D.bimg16, (size_t)MlpBwdImgB::TOTAL_F * 4)); HIPCHK(hipMalloc(&D.bidx16, ib.size() * 4));
-            HIPCHK(hipMemset(D.bimg16, 0, (size_t)MlpBwdImgB::TOTAL_F * 4));
+            HIPCHK(hipMalloc(&D.bimg16, (size_t)MlpBwdImgH::TOTAL_F * 4)); HIPCHK(hipMalloc(&D.bidx16, ib.size() * 4));
+            HIPCHK(hipMemset(D.bimg16, 0, (size_t)MlpBwdImgH::TOTAL_F * 4));
             HIPCHK(hipMemcpy(D.bidx16, ib.data(), ib.size() * 4, hipMemcpyHostToDevice));
+            std::vector<int> invh(n4, -1);
+            for (size_t k = 0; k < ib.size(); ++k) if (ib[k] >= 0) { if (invh[ib[k]] != -1) return fail("decoder %d: parameter %d appears twice in the fp16 backward image", w, ib[k]); invh[ib[k]] = (int)k; }
+            HIPCHK(hipMalloc(&D.invh, n4 * 4));
+            HIPCHK(hipMemcpy(D.invh, invh.data(), n4 * 4, hipMemcpyHostToDevice));
             std::vector<int> inv16(n4, -1);
             for (size_t k = 0; k < i16.size(); ++k) if (i16[k] >= 0) { if (inv16[i16[k]] != -1) return fail("decoder %d: parameter %d appears twice in the bf16 image", w, i16[k]); inv16[i16[k]] = (int)k; }
             HIPCHK(hipMalloc(&D.inv16, n4 * 4));
@@ -1398,7 +1413,7 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     A.g_rays_o = g_ro; A.g_rays_d = g_rd;
     A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
     A.flags = flags;
-    if (!train && w != 0 && !rays) CHK(ensure_bimg16(c, w));
+    if (w != 0 && !train && !rays) CHK(ensure_bimg16(c, w));      // the frozen chain on fp16 pieces
     if (train && w != 2) {
         if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
         A.hsave = c->ws.hsave[w];
@@ -1755,7 +1770,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
 #else
         A.flags = flags & 0xffu;
 #endif
-        if (!train && w != 0 && !rays) CHK(ensure_bimg16(c, w));
+        if (w != 0 && !train && !rays) CHK(ensure_bimg16(c, w));
         if (train && w != 2) {
             if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
             A.hsave = c->ws.hsave[w];
@@ -2232,7 +2247,8 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
             adam_consts(lr[NSK_GROUP_DECODERS], b1, b2, step, S.step_size, S.bc2s);
             S.p = D.p; S.g = c->slab + D.g_off; S.m = D.m; S.v = D.s; S.idx = nullptr; S.nidx = 0; S.n = n4;
             S.inv_f = D.finv; S.inv_b = D.binv; S.fimg = D.fimg; S.bimg = D.bimg;
-            D.bimg16_dirty = true;
+            if (D.bimg16) { S.invh = D.invh; S.imgh = reinterpret_cast<unsigned short*>(D.bimg16); S.imgh_tail = D.bimg16 + MlpBwdImgH::P_WO; S.btail_off = MlpBwdImg::P_WO; }
+            else D.bimg16_dirty = true;
             if (c->pend_w == w) {
                 S.slabs = c->ws.dec_slabs; S.nslabs = c->pend_nb; S.slab_stride = n4; c->pend_w = -1;
                 blocks += (n4 / 4 + 7) / 8 - (n4 / 4 + 255) / 256;         // 8 float4 per block (see k_adam_multi)

@@ -463,22 +463,67 @@ __device__ __forceinline__ void mac_block_h(const FragH& a0, const FragH& a1, co
     accL[0] = mfma_h(a0.h, x.l, accL[0]); accL[1] = mfma_h(a1.h, x.l, accL[1]);
     accL[0] = mfma_h(a0.l, x.h, accL[0]); accL[1] = mfma_h(a1.l, x.h, accL[1]);
 }
+// the pieces of (bit ? x : 0) from the pieces of x (see mask_block): bit j <-> element j of the block
+__device__ __forceinline__ H2 mask_block_h(const H2& x, unsigned bits)
+{
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 h = __builtin_bit_cast(u4, x.h), l = __builtin_bit_cast(u4, x.l);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned lo = 0u - ((bits >> (2 * d)) & 1u), hi = 0u - ((bits >> (2 * d + 1)) & 1u);
+        const unsigned k = (lo & 0xffffu) | (hi & 0xffff0000u);
+        h[d] &= k; l[d] &= k;
+    }
+    H2 r;
+    r.h = __builtin_bit_cast(h8, h); r.l = __builtin_bit_cast(h8, l);
+    return r;
+}
 
-// backward (transposed) image of an MLP decoder in bf16 pieces, for the frozen-decoder chain without ray gradients:
-// fragment group FT(l) + rt: fc[l]^T rows 16rt.. (grid features 0..31), WT(l) + rt: pts_linear[l]^T (h part), K = 32 each
-struct MlpBwdImgB {
-    static constexpr int NFG = 18;
-    static constexpr int FRAG_BYTES = NFG * 3 * 1024;
+// Backward (transposed) image of an MLP decoder in fp16 pieces (two per weight, the low one 2048-fold), K = 32 output features each:
+// fragment group FT(l) + rt: fc[l]^T rows 16rt.. (grid features 0..31); WT(l) + rt: pts_linear[l]^T (h part); W0ET / W3ET + rt: the
+// e parts of pts_linear[0] / [3] transposed (96 rows, rt < 6).  Used by the frozen decoders' chain (the first 18 groups) and by the
+// trainable decoder's chain (all of it).  The fp32 tail is the one of MlpBwdImg (output weight, embedding matrix): same total size.
+struct MlpBwdImgH {
+    static constexpr int NFG = 30;
+    static constexpr int FRAG_BYTES = NFG * 2 * 1024;
     static constexpr int P_WO = FRAG_BYTES / 4;      // float offset of the output weight [4][32]
-    static constexpr int TOTAL_F = P_WO + 128;
+    static constexpr int P_BM = P_WO + 128;          // embedding B [3][96]
+    static constexpr int TOTAL_F = P_BM + 288;
+    static constexpr int W0ET = 18, W3ET = 24;
     __host__ __device__ static constexpr int FT(int l) { return 2 * l; }
     __host__ __device__ static constexpr int WT(int l) { return 10 + 2 * (l - 1); }
 };
-// acc[rt] += (fragment groups fg0, fg0+1) x   (six bf16 MFMAs per row tile)
-__device__ __forceinline__ void gemm_b(const bf8* __restrict__ img, int fg0, int lane, const B3& x, f4 (&acc)[2])
+// accH[rt] / accL[rt] += (fragment groups fg0, fg0+1) x   (three fp16 MFMAs per row tile)
+__device__ __forceinline__ void gemm_h(const h8* __restrict__ img, int fg0, int lane, const H2& x, f4 (&accH)[2], f4 (&accL)[2])
 {
-    const Frag3 a0 = load_frag(img, fg0, lane), a1 = load_frag(img, fg0 + 1, lane);
-    mac_block(a0, a1, x, acc);
+    const FragH a0 = load_frag_h(img, fg0, lane), a1 = load_frag_h(img, fg0 + 1, lane);
+    mac_block_h(a0, a1, x, accH, accL);
+}
+// [96 x 32] transposed e-part product: acc[0..5] += W?ET x, as three 32-row slices
+__device__ __forceinline__ void gemm_e_h(const h8* __restrict__ img, int fg0, int lane, const H2& x, f4 (&acc)[6])
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        f4 tH[2] = {acc[2 * a], acc[2 * a + 1]}, tL[2] = {(f4)(0.f), (f4)(0.f)};
+        gemm_h(img, fg0 + 2 * a, lane, x, tH, tL);
+        acc[2 * a] = tH[0] + tL[0] * (1.f / NSK_H16_SCALE); acc[2 * a + 1] = tH[1] + tL[1] * (1.f / NSK_H16_SCALE);
+    }
+}
+// A chain on fp16 pieces runs on a per-sample power-of-two multiple of the upstream gradient (largest component in [2^-4, 2^-3)):
+// a sample's gradients span many decades between samples (transmittance), fp16 does not; the chain is linear per sample, so the
+// scale is exact and comes off again where a result leaves the chain.  Returns the unscale factor, scales g in place.
+template <int OD>
+__device__ __forceinline__ float chain_scale(float (&g)[OD])
+{
+    float m = 0.f;
+#pragma unroll
+    for (int o = 0; o < OD; ++o) m = fmaxf(m, fabsf(g[o]));
+    int e = __builtin_amdgcn_frexp_expf(m);
+    e = max(-100, min(100, e));
+    const float sc = __builtin_ldexpf(1.f, -e - 3);
+#pragma unroll
+    for (int o = 0; o < OD; ++o) g[o] *= sc;
+    return __builtin_ldexpf(1.f, e + 3);
 }
 
 // the same in two steps (loads first, weighting later) so that independent work can sit between them
@@ -1144,10 +1189,10 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     constexpr bool XYZ = WHICH != 0;
     constexpr int OD = WHICH == 3 ? 4 : 1;
     constexpr bool NEED_E = XYZ && RAYS;
-    // B16: without ray gradients an MLP decoder's chain is ten K=32 products per tile; they run on the bf16 matrix cores with
-    // 3-piece operands (fp32-accurate, nsk_bf16.h) instead of the fp32 MFMA, which blocks the SIMD's vector issue
+    // B16: without ray gradients an MLP decoder's chain is nine K=32 products per tile; they run on the fp16 matrix cores with
+    // 2-piece operands (22 significant bits, nsk_bf16.h) instead of the fp32 MFMA, which blocks the SIMD's vector issue
     constexpr bool B16 = XYZ && !RAYS;
-    constexpr int IMG_F = B16 ? MlpBwdImgB::TOTAL_F : (XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL);
+    constexpr int IMG_F = B16 ? MlpBwdImgH::TOTAL_F : (XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL);
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
@@ -1158,11 +1203,11 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     }
     __syncthreads();
     const f4* bimg = smem;
-    const bf8* img16 = reinterpret_cast<const bf8*>(smem);
+    const h8* img16 = reinterpret_cast<const h8*>(smem);
     const float* bimgf = reinterpret_cast<const float*>(smem);
     const float* Bm = nullptr;
     if constexpr (XYZ && !B16) Bm = bimgf + MlpBwdImg::P_BM;
-    const float* Wo = B16 ? bimgf + MlpBwdImgB::P_WO : (XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO);
+    const float* Wo = B16 ? bimgf + MlpBwdImgH::P_WO : (XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO);
 
     const int ntasks = (A.M + 15) >> 4;
     // The next tile's loads are issued at the top of this tile and forced to have landed before this tile's scatter: vmcnt
@@ -1204,6 +1249,8 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
             else gout[0] = gr[3];
         }
+        float unscale = 1.f;
+        if constexpr (B16) unscale = chain_scale<OD>(gout);
         const unsigned long long mask = nx.mask;
         stage(tile_of(k + 1, wg, nw, tsh), mm_next, nx);
         mm_next = slot_sample(A, slot_of(tile_of(k + 2, wg, nw, tsh)));
@@ -1219,14 +1266,14 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                 for (int o = 0; o < OD; ++o) s += Wo[32 * o + 16 * r + 4 * g + i] * gout[o];
                 gh[r][i] = s;
             }
-        f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
+        f4 gc[2] = {(f4)(0.f), (f4)(0.f)}, gcL[2] = {(f4)(0.f), (f4)(0.f)};
         f4 ge[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
 #pragma unroll
         for (int l = 4; l >= 0; --l) {
-            B3 xg;
-            if constexpr (B16) { xg = split_block(gh[0], gh[1]); gemm_b(img16, MlpBwdImgB::FT(l), lane, xg, gc); }
+            H2 xg;
+            if constexpr (B16) { xg = split_block_h(gh[0], gh[1]); gemm_h(img16, MlpBwdImgH::FT(l), lane, xg, gc, gcL); }
             else if constexpr (XYZ) gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);       // g_c += fc[l]^T g_h
             f4 ga[2];
             if constexpr (!B16) {
@@ -1237,10 +1284,10 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             }
             if constexpr (B16) {
                 if (l >= 1) {
-                    const B3 xa = mask_block(xg, (unsigned)(mask >> (8 * l)) & 0xffu);      // g_a = ReLU'(.) g_h, already in pieces
-                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)};
-                    gemm_b(img16, MlpBwdImgB::WT(l > 0 ? l : 1), lane, xa, ghn);
-                    gh[0] = ghn[0]; gh[1] = ghn[1];
+                    const H2 xa = mask_block_h(xg, (unsigned)(mask >> (8 * l)) & 0xffu);      // g_a = ReLU'(.) g_h, already in pieces
+                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)}, ghl[2] = {(f4)(0.f), (f4)(0.f)};
+                    gemm_h(img16, MlpBwdImgH::WT(l > 0 ? l : 1), lane, xa, ghn, ghl);
+                    gh[0] = ghn[0] + ghl[0] * (1.f / NSK_H16_SCALE); gh[1] = ghn[1] + ghl[1] * (1.f / NSK_H16_SCALE);
                 }
             } else if constexpr (XYZ) {
                 if constexpr (NEED_E) {
@@ -1262,6 +1309,9 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                     gh[0] = ghn[0]; gh[1] = ghn[1];
                 }
             }
+        }
+        if constexpr (B16) {        // join the two accumulator sets and take the sample's scale off
+            gc[0] = (gc[0] + gcL[0] * (1.f / NSK_H16_SCALE)) * unscale; gc[1] = (gc[1] + gcL[1] * (1.f / NSK_H16_SCALE)) * unscale;
         }
         // opaque use: the staged registers must hold their data here, i.e. the loads retire before the first atomic below
         asm volatile("" : "+v"(nx.r.z), "+v"(nx.r.o[0]), "+v"(nx.r.o[1]), "+v"(nx.r.o[2]), "+v"(nx.r.d[0]), "+v"(nx.r.d[1]), "+v"(nx.r.d[2]),

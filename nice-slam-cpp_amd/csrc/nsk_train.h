@@ -109,8 +109,9 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h01, u
 }
 
 // transpose one D-layout quad (16 feature rows x this wave's 16 samples) into the panel at row `row0`: 16-bit stores (low / high half)
-__device__ __forceinline__ void pn_put(char* __restrict__ pn, int moff, int row0, int wave, int lane, f4 x)
+__device__ __forceinline__ void pn_put(char* __restrict__ pn, int moff, int row0, int wave, int lane, f4 x, float us = 1.f)
 {
+    x *= us;                                // (gradients of a chain on fp16 pieces: the sample's scale comes off here)
     const int j = lane & 15, g = lane >> 4;
     char* ph = pn + (row0 + 4 * g) * PN_RB + (16 * wave + j) * 2;
 #pragma unroll
@@ -215,6 +216,11 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     // is recomputed here and the backward (transposed) image stays in LDS for the whole kernel.  The fine decoder (64 input
     // features, images too large for LDS beside the panel) keeps the older form: forward recompute, fragments streamed from L2.
     constexpr bool SAVED = WHICH != 2;
+    // H16: the chain's transposed products (g_c, g_h, g_e) on the fp16 matrix cores with 2-piece operands and a per-sample scale
+    // (nsk_device.h: MlpBwdImgH, chain_scale) instead of 240 fp32 MFMAs per tile; the image has the size of the fp32 one.
+    // Built, parity-green and OFF: 90 MFMAs of 16 cycles replace 240 of 32, and the iteration did not get shorter (K3: 27.7 against
+    // 27.1 us per 128 samples, 59 spilled VGPRs) -- the role waits on its panel phases, not on issue slots.
+    constexpr bool H16 = false && XYZ && SAVED;
     typedef MlpFwdImg<CQ> FI;
     typedef TrainPlan<WHICH> PL;
     constexpr PL plan{};
@@ -226,14 +232,17 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     char* pn = reinterpret_cast<char*>(smf + IMG_F);     // shared panel (plane H; plane M at + PM)
     constexpr int PM = PN_MOFF(CQ);
     float* scratch = smf + IMG_F + wave * 1056;     // per-wave scatter scratch (NSK_SCRATCH_FLOATS <= 1056): the head of plane H, idle between the last phase and phase OUT
-    copy_image_to_lds<512>(smem, A.bimg, IMG_F / 4);
+    static_assert(!H16 || MlpBwdImgH::TOTAL_F == BWD_F, "the fp16 backward image takes the fp32 image's place in LDS");
+    copy_image_to_lds<512>(smem, H16 ? reinterpret_cast<const f4*>(A.bimg16) : A.bimg, IMG_F / 4);
     __syncthreads();
+    const h8* imgh = reinterpret_cast<const h8*>(smem);
     const f4* fimg = A.img;                         // !SAVED only: forward fragments from L2
     const float* fimgf = reinterpret_cast<const float*>(fimg);
     const f4* bimg = SAVED ? smem : A.bimg;
     const float* bimgf = reinterpret_cast<const float*>(bimg);
     const float* Bm = nullptr;                      // embedding matrix [3][96]
     if constexpr (XYZ) Bm = SAVED ? bimgf + MlpBwdImg::P_BM : fimgf + FI::P_BM;
+    static_assert(MlpBwdImgH::P_BM == MlpBwdImg::P_BM && MlpBwdImgH::P_WO == MlpBwdImg::P_WO, "same fp32 tail in both images");
     const float* Bmb = Bm;
     const float* Wo = SAVED ? bimgf + (XYZ ? MlpBwdImg::P_WO : CoarseBwdImg::P_WO) : fimgf + FI::P_WO;
 
@@ -292,6 +301,11 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
             else gout[0] = gr[3];
         }
+        f4 go;                                           // G of phase OUT: g_out itself (rows >= OD zero)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) go[i] = (4 * g + i) < OD ? gout[(4 * g + i) < OD ? (4 * g + i) : 0] : 0.f;
+        float us = 1.f;                                  // H16: gout becomes a power-of-two multiple of itself, us takes the scale off again
+        if constexpr (H16) us = chain_scale<OD>(gout);
         Act<CQ> C;
         ActC CC;
         f4 xcos[6];
@@ -322,9 +336,6 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             }
         // ---- phase OUT: G = g_out (rows >= OD zero), X = h4 ------------------------------------------------
         {
-            f4 go;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) go[i] = (4 * g + i) < OD ? gout[(4 * g + i) < OD ? (4 * g + i) : 0] : 0.f;
             if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, go);
             const f4* h4 = XYZ ? C.h[4] : CC.h[4];
             if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS, wave, lane, h4[0]);
@@ -353,11 +364,16 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             if constexpr (SAVED && l >= 2) load_h(std::integral_constant<int, l - 2>{});
             if constexpr (l == 2) NSK_PH(20);
             if constexpr (XYZ) {
-                gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);                 // g_c += fc[l]^T g_h
+                if constexpr (H16) {        // (the low accumulators join g_c layer by layer: eight registers fewer across the panel phases)
+                    const H2 xg = split_block_h(gh[0], gh[1]);
+                    f4 gl[2] = {(f4)(0.f), (f4)(0.f)};
+                    gemm_h(imgh, MlpBwdImgH::FT(l), lane, xg, gc, gl);
+                    gc[0] += gl[0] * (1.f / NSK_H16_SCALE); gc[1] += gl[1] * (1.f / NSK_H16_SCALE);
+                } else gemm<2, 2>(bimg, MlpBwdImg::FT(l), lane, gh, gc);                 // g_c += fc[l]^T g_h
                 if constexpr (l == 2) NSK_PH(21);
                 // ---- phase FC_l: G = g_h, X = c ------------------------------------------------------------
-                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, gh[0]);
-                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 16, wave, lane, gh[1]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, gh[0], us);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 16, wave, lane, gh[1], us);
 #pragma unroll
                 for (int q = 0; q < CQ; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_GROWS + 16 * q, wave, lane, C.xc[q]);
                 if constexpr (l == 2) NSK_PH(22);
@@ -375,10 +391,12 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
+            H2 xa;
+            if constexpr (H16) xa = split_block_h(ga[0], ga[1]);       // (split again rather than masking g_h's pieces: those would stay live across phase FC)
             // ---- phase W_l: G = g_a, X = layer input ----------------------------------------------------------
             {
-                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, ga[0]);
-                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 16, wave, lane, ga[1]);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, ga[0], us);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 16, wave, lane, ga[1], us);
                 if constexpr (XYZ) {
                     if constexpr (l == 0) {
                     } else if constexpr (l == 3) {
@@ -419,7 +437,17 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 }
             }
             if constexpr (l == 3) NSK_PH(15); NSK_PHI(15);
-            if constexpr (XYZ) {
+            if constexpr (H16) {
+                if constexpr (l == 3) gemm_e_h(imgh, MlpBwdImgH::W3ET, lane, xa, ge);
+                if constexpr (l == 3) NSK_PH(16); NSK_PHI(16);
+                if constexpr (l == 0) gemm_e_h(imgh, MlpBwdImgH::W0ET, lane, xa, ge);
+                if constexpr (l >= 1) {
+                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)}, ghl[2] = {(f4)(0.f), (f4)(0.f)};
+                    gemm_h(imgh, MlpBwdImgH::WT(l), lane, xa, ghn, ghl);
+                    gh[0] = ghn[0] + ghl[0] * (1.f / NSK_H16_SCALE); gh[1] = ghn[1] + ghl[1] * (1.f / NSK_H16_SCALE);
+                    if constexpr (l == 2) NSK_PH(30);
+                }
+            } else if constexpr (XYZ) {
                 if constexpr (l == 3) gemm_e(bimg, MlpBwdImg::W3ET, lane, ga, ge);
                 if constexpr (l == 3) NSK_PH(16); NSK_PHI(16);
                 if constexpr (l == 0) gemm_e(bimg, MlpBwdImg::W0ET, lane, ga, ge);
@@ -452,6 +480,9 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         NSK_PH(7); NSK_PHI(7);
         if (it + 1 < iters) { stage_a(it + 1, mm_next, nx); mm_next = slot_sample(A, slot_of(it + 2)); }
         NSK_PH(8); NSK_PHI(8);
+        if constexpr (H16) {        // take the sample's scale off g_c (g_e keeps it: phase DB and g_p below)
+            gc[0] *= us; gc[1] *= us;
+        }
         float gp[3] = {0.f, 0.f, 0.f};
         asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));     // opaque: forces the recomputation below instead of keeping T / cos live
         tri_setup(A.grid, A.bound, px, py, pz, T);
@@ -464,7 +495,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
                 f4 pq;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
-                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, pq);
+                if (!NSK_DBG(A, 14)) pn_put(pn, PM, 0, wave, lane, pq, us);          // (H16: g_s below still carries the sample's scale; it comes off on this side of the product)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) if (!NSK_DBG(A, 14)) pn_put(pn, PM, PN_EROWS(CQ) + 16 * q, wave, lane, ge[q]);
                 NSK_BAR();
@@ -481,6 +512,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { gp[0] += ge[q][i] * b0[i]; gp[1] += ge[q][i] * b1[i]; gp[2] += ge[q][i] * b2[i]; }
                 }
+                if constexpr (H16) { gp[0] *= us; gp[1] *= us; gp[2] *= us; }
             }
         }
         if constexpr (RAYS) {

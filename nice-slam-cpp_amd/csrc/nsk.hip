@@ -723,6 +723,8 @@ struct nsk_ctx {
     bool roctx = false;                     // roctx ranges around every profiled launch group (libroctx64, loaded on demand)
     int tune_fwd_fine_cost = 0, tune_fwd_color_cost = 0;     // experiments: forward role costs (nsk_set_tuning "fwd_fine_cost" / "fwd_color_cost")
     int tune_skew = 0;                      // start offset of the upper four waves of a decoder workgroup, x 1024 cycles (wave_skew, nsk_device.h)
+    bool median_fused_pending = false;
+    int tune_no_fused_median = 0;           // 1: the Tracker's median threshold in its own launch even where the fused form applies (experiments, tests)
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
@@ -879,7 +881,21 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
     return 0;
 }
 
-extern "C" int nsk_sync(nsk_ctx* c) { if (!c) return fail("null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+extern "C" int nsk_sync(nsk_ctx* c)
+{
+    if (!c) return fail("null ctx");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->median_fused_pending) {          // k_composite mode 4 ran since the last sync: did its grid barrier time out?
+        c->median_fused_pending = false;
+        unsigned bar[3] = {0, 0, 0};
+        HIPCHK(hipMemcpy(bar, c->scal + 5, sizeof(bar), hipMemcpyDeviceToHost));
+        if (bar[2]) {
+            HIPCHK(hipMemset(c->scal + 5, 0, sizeof(bar)));
+            return fail("nsk_track_step: the grid barrier of the fused median timed out (threshold was infinite for that step); nsk_set_tuning(\"no_fused_median\", 1) selects the three-launch form");
+        }
+    }
+    return 0;
+}
 extern "C" void* nsk_stream(nsk_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 static int repack16(nsk_ctx* c, int w);
@@ -902,6 +918,7 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
 {
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
+    if (!strcmp(key, "no_fused_median")) { c->tune_no_fused_median = value; return 0; }
     if (!strcmp(key, "fwd_fine_cost")) { c->tune_fwd_fine_cost = value; return 0; }
     if (!strcmp(key, "fwd_color_cost")) { c->tune_fwd_color_cost = value; return 0; }
     if (!strcmp(key, "skew")) { if (value < 0 || value > 299) return fail("nsk_set_tuning: skew out of range"); c->tune_skew = value; return 0; }
@@ -1926,14 +1943,18 @@ extern "C" int nsk_track_step(nsk_ctx* c, int stage, int N, const float* ro, con
     CHK(forward_core(c, stage, N, S, ro, rd, gt, gtmax, true, sort_pays(c, stage, N * S, flags)));
     CompArgs A;
     comp_args(c, A, stage, N, S, ro, rd);
-    if (handle_dynamic) {                                      // forward pass for the median (Tracker.cpp:69-70)
+    // One launch (k_composite mode 4: residuals -> grid barrier -> median -> loss and backward) while the grid is at most one
+    // workgroup per CU, i.e. certainly resident as a whole; three launches otherwise (and in the deterministic debug mode)
+    const bool fused_median = handle_dynamic && !c->deterministic && !c->tune_no_fused_median && N <= NSK_MEDIAN_FUSED_MAX && (N + 3) / 4 <= c->num_cu;
+    if (handle_dynamic && !fused_median) {                     // forward pass for the median (Tracker.cpp:69-70)
         A.mode = 0; A.depth = c->ws.tmp_depth;
         k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
         CHK(median_thr(c, N, gt, c->ws.tmp_depth));
         A.depth = nullptr;
     }
-    A.mode = 3; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
+    A.mode = fused_median ? 4 : 3; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
     A.thr = c->scal + 1; A.handle_dynamic = handle_dynamic; A.detach_var = detach_var; A.loss = c->ws.ray_loss;
+    if (fused_median) { c->median_fused_pending = true; A.resid = c->ws.tmp_depth; A.bar = reinterpret_cast<unsigned*>(c->scal + 5); A.thr_out = c->scal + 1; }
     if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
     { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());

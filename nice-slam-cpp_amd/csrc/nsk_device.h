@@ -941,6 +941,7 @@ struct CompArgs {
     const float* g_rgb; const float* g_depth; const float* g_var;            // mode 1
     const float* gt_depth; const float* gt_color; float w_color; int use_color;   // modes 2,3
     const float* thr; int handle_dynamic; int detach_var;                     // mode 3 (thr: device scalar)
+    float* resid; unsigned* bar; float* thr_out;                              // mode 4: per-ray |gt - depth| [N], grid barrier {arrived, left, timed out}, 10 x median
     float* loss;                                                              // modes 2,3: per-ray loss [N] or nullptr
     float* g_raw;                                                             // [M][4]
     float* g_rays_o; float* g_rays_d;                                         // [N][3] seeds or nullptr
@@ -950,11 +951,19 @@ struct CompArgs {
 
 __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
+// mode 0: forward only; 1: backward from given output gradients; 2: Mapper loss; 3: Tracker loss with the median threshold read from
+// A.thr; 4: Tracker loss with the threshold computed HERE -- the residuals of all rays meet at a grid barrier (every workgroup
+// is resident: the host uses this mode only while the grid has at most one workgroup per CU), each workgroup then finds
+// 10 x the lower median by rank counting.  One launch instead of composite + k_median_thr + composite (Tracker.cpp:67-71).
+#define NSK_MEDIAN_FUSED_MAX 1024         // rays (LDS copy of the residuals; the host also caps the grid at one workgroup per CU)
 __global__ __launch_bounds__(256) void k_composite(CompArgs A)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= A.N) return;
+    int n = blockIdx.x * 4 + wave;
+    if (n >= A.N) {
+        if (A.mode != 4) return;
+        n = A.N - 1;                       // mode 4 has workgroup barriers: a spare wave of the last workgroup repeats the last ray (same stores)
+    }
     const int S = A.S;
     const bool act = lane < S;
     const size_t m = (size_t)n * S + (act ? lane : S - 1);
@@ -999,9 +1008,61 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
         if (A.rgb) { A.rgb[3 * n] = cr; A.rgb[3 * n + 1] = cg; A.rgb[3 * n + 2] = cb; }
     }
     if (A.mode == 0) return;
+    const bool kept = !A.keep || A.keep[n];
+    float thr_here = 0.f;
+    if (A.mode == 4) {
+        __shared__ __attribute__((aligned(16))) float rs[NSK_MEDIAN_FUSED_MAX];
+        __shared__ float s_thr;
+        __shared__ int s_valid;
+        // The residuals travel as device-scope atomics (they are written through to the coherence point) and the counter is bumped only
+        // after this workgroup's stores have been acknowledged (vmcnt): no release / acquire fence, which on this part writes back and
+        // invalidates the whole L2 of the XCD (measured: the launch took 22 us with __threadfence(), three launches took 8)
+        if (lane == 0) __hip_atomic_store(&A.resid[n], kept ? fabsf(A.gt_depth[n] - D) : NSK_INF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // masked rays sort to the end (k_median_thr)
+        if (threadIdx.x == 0) { s_thr = NSK_INF; s_valid = 0; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // grid barrier: device-scope counter; bounded wait (a grid that is not resident as a whole must not hang the GPU: it leaves
+            // with the threshold at infinity and the flag bar[2] set, which nsk_sync reports)
+            __hip_atomic_fetch_add(&A.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(&A.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 20)) { A.bar[2] = 1u; break; }
+            }
+        }
+        __syncthreads();
+        const int N4 = (A.N + 3) & ~3;
+        for (int i = threadIdx.x; i < N4; i += 256) {
+            const float v = i < A.N ? __hip_atomic_load(&A.resid[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NSK_INF;
+            rs[i] = v;
+            if (v < NSK_INF) atomicAdd(&s_valid, 1);
+        }
+        __syncthreads();
+        const int target = (max(s_valid, 1) - 1) / 2;          // torch.median: the lower median of the valid residuals
+        for (int i = threadIdx.x; i < A.N; i += 256) {         // rank of residual i in the order (value, index); four comparisons per LDS read
+            const float v = rs[i];
+            int rank = 0;
+            for (int k = 0; k < N4; k += 4) {
+                const f4 u = *reinterpret_cast<const f4*>(rs + k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rank += (u[q] < v || (u[q] == v && k + q < i)) ? 1 : 0;
+            }
+            if (rank == target) s_thr = 10.f * v;
+        }
+        __syncthreads();
+        thr_here = s_thr;
+        if (threadIdx.x == 0) {
+            if (blockIdx.x == 0 && A.thr_out) *A.thr_out = thr_here;
+            const unsigned old = __hip_atomic_fetch_add(&A.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == gridDim.x - 1) {         // the last workgroup to leave re-arms the barrier for the next launch
+                __hip_atomic_store(&A.bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     // ---- seed gradients -------------------------------------------------------------------------------
     float gD = 0.f, gV = 0.f, gC[3] = {0.f, 0.f, 0.f};
-    const bool kept = !A.keep || A.keep[n];
     if (!kept) {
         // a masked ray contributes exactly nothing, whatever its rendering came out as (a frame that looks out of the bound renders
         // inf / NaN, and 0 * NaN would otherwise reach the grids: tests/test_gpu_configs.py::test_fully_masked_batch_is_a_no_op)
@@ -1026,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
                 for (int k = 0; k < 3; ++k) gC[k] = -A.w_color * sgnf(rc[k]);
             }
         } else {                                                // Tracker.cpp:67-82
-            bool mk = gtd > 0.f && (!A.handle_dynamic || fabsf(r) < *A.thr);
+            bool mk = gtd > 0.f && (!A.handle_dynamic || fabsf(r) < (A.mode == 4 ? thr_here : *A.thr));
             if (mk) {
                 float u = sqrtf(V + 1e-10f);
                 lsum += fabsf(r) / u;

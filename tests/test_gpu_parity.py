@@ -374,6 +374,31 @@ def test_tracking_steps_match_oracle(oracle32, oracle64):
     print("tracking: grad err hip %.2e oracle32 %.2e | pose err hip %.2e oracle32 %.2e" % (e_g, e_g_ref, e_p, e_p_ref))
 
 
+@pytest.mark.parametrize("n_rays,masked", [(200, False), (37, True), (1023, False), (1500, False)])
+def test_tracker_median_in_the_composite_launch(n_rays, masked):
+    """Tracker.cpp:67-71: the 10 x median threshold computed inside the loss launch (k_composite mode 4: residuals, grid barrier, rank
+    counting) gives the bits of the three-launch form (composite, k_median_thr, composite); ray counts that are not a multiple of the
+    four rays of a workgroup, a ray mask, and a batch above the fused form's limit (1500 rays: both runs take the three launches)"""
+    sc = _scene(33, grid_std=0.3)
+    rays = scenes.make_rays(34, n_rays, sc["bound"], n_frames=1, zero_frac=0.1)
+    out = {}
+    for fused in (1, 0):
+        ctx = make_ctx(sc)
+        ctx.set_tuning("no_fused_median", 0 if fused else 1)
+        if masked:
+            keep = (np.arange(n_rays) % 3 != 0).astype(np.uint8)
+            ctx.set_ray_mask(cu(keep, torch.uint8))
+        ro, rd, gd, gc = cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"]), cu(rays["gt_color"])
+        g_ro = torch.empty_like(ro); g_rd = torch.empty_like(rd); loss = torch.zeros(1, device="cuda")
+        for _ in range(3):          # the barrier re-arms itself: three launches in a row
+            ctx.track_step("color", ro, rd, gd, gc, -1.0, 0.5, True, True, True, flags=4, loss=loss, g_rays=(g_ro, g_rd))
+        ctx.sync()
+        out[fused] = (float(loss), g_ro.cpu().numpy().copy(), g_rd.cpu().numpy().copy())
+    assert out[1][0] == out[0][0], (out[1][0], out[0][0])
+    # the ray gradients are sums of atomics over the samples' tiles: equal up to the order of those adds
+    assert rel_l2(out[1][1], out[0][1]) < 1e-6 and rel_l2(out[1][2], out[0][2]) < 1e-6
+
+
 @pytest.mark.parametrize("stage", ["fine", "color"])
 def test_forward_bf16_split_mode_matches_oracle(stage, oracle32, oracle64):
     """matmul modes 1 (fp32 operands as three bf16 pieces, six bf16 MFMAs per product) and 2 (two fp16 pieces, 22 significant

@@ -1382,7 +1382,7 @@ static int check_stage(nsk_ctx* c, int stage)
 static void fill_args(nsk_ctx* c, DecArgs& A, int w, int M, int S, const float* ro, const float* rd, const float* pts)
 {
     memset(&A, 0, sizeof(A));
-    A.rays_o = ro; A.rays_d = rd; A.z = c->ws.z; A.pts = pts; A.M = M; A.S = S;
+    A.rays_o = ro; A.rays_d = rd; A.z = c->ws.z; A.pts = pts; A.M = M; A.S = S; A.S_magic = S > 1 ? (unsigned)((0x100000000ull + (unsigned)S - 1) / (unsigned)S) : 0u;
     A.perm = (c->sorted && !pts) ? c->ws.perm : nullptr;
     memcpy(A.bound, c->R.bound, sizeof(A.bound));
     A.grid = grid_dev(c, w, false);
@@ -1696,7 +1696,7 @@ static int common_checks(nsk_ctx* c, int stage, int N, const float* ro, const fl
     CHK(check_stage(c, stage));
     HIPCHK(hipSetDevice(c->device));
     int S = c->R.n_samples + (gt ? c->R.n_surface : 0);
-    if ((long long)N * S > 0x7fffffffLL / 4) return fail("N*S too large");
+    if ((long long)N * S >= (1LL << 26)) return fail("N*S too large (%lld samples; at most 2^26 - 1 per call)", (long long)N * S);      // (also the range of ray_of)
     CHK(ensure_ws(c, N, N * S));
     *S_out = S;
     return 0;

@@ -579,7 +579,9 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, int g, f4
     acc[1] = *reinterpret_cast<const f4*>(b + 16 + 4 * g);
 }
 
-// ReLU in place, returns the 8 sign bits (bit r*4+i)
+// ReLU in place, returns the 8 "input was > 0" bits (bit r*4+i).  max(x, 0) is >= +0, so its bit pattern as an unsigned integer is
+// zero exactly when the ReLU's derivative is (x <= 0, or NaN -- v_max_f32 returns the other operand): min(bits, 1) is the bit.
+// Three vector instructions per element and no compare (a v_cmp feeding v_cndmask also costs wait states); NaN inputs become 0.
 __device__ __forceinline__ uint32_t relu_mask(f4 (&a)[2])
 {
     uint32_t m = 0;
@@ -587,8 +589,9 @@ __device__ __forceinline__ uint32_t relu_mask(f4 (&a)[2])
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (a[r][i] > 0.f) m |= 1u << (r * 4 + i);
-            else a[r][i] = 0.f;
+            const float y = fmaxf(a[r][i], 0.f);
+            a[r][i] = y;
+            m |= min(__float_as_uint(y), 1u) << (r * 4 + i);
         }
     return m;
 }
@@ -727,6 +730,7 @@ struct DecArgs {
     const float* rays_o; const float* rays_d; const float* z; const float* pts;
     const int* perm;          // cell-sorted sample order (k_sort_place): tile slot t -> sample perm[t]; nullptr = identity
     int M, S;
+    unsigned S_magic;         // ceil(2^32 / S) (0 for S = 1): see ray_of; the host keeps M below 2^26
     float bound[6];
     GridD grid, grid_mid;
     const f4* img;            // forward image (global)
@@ -757,10 +761,12 @@ __device__ __forceinline__ void wave_skew(const DecArgs& A, int wave, int nw)
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
 }
 
+// ray of sample mm = mm / S without the generic division (~25 vector instructions): umulhi by ceil(2^32 / S), exact for mm < 2^32 / S
+__device__ __forceinline__ int ray_of(const DecArgs& A, int mm) { return A.S_magic ? (int)__umulhi((unsigned)mm, A.S_magic) : mm; }
 __device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px, float& py, float& pz, float& zz, int& n)
 {
     if (A.pts) { px = A.pts[3 * mm]; py = A.pts[3 * mm + 1]; pz = A.pts[3 * mm + 2]; zz = 0.f; n = 0; return; }
-    n = mm / A.S;
+    n = ray_of(A, mm);           // = mm / A.S (the generic division is ~25 vector instructions)
     zz = A.z[mm];
     px = add_rn(A.rays_o[3 * n], mul_rn(A.rays_d[3 * n], zz));           // reference src/Renderer.cpp:121
     py = add_rn(A.rays_o[3 * n + 1], mul_rn(A.rays_d[3 * n + 1], zz));
@@ -772,7 +778,7 @@ struct SampleRaw { float z, o[3], d[3]; };
 __device__ __forceinline__ void sample_load(const DecArgs& A, int mm, SampleRaw& R)
 {
     if (A.pts) { R.o[0] = A.pts[3 * mm]; R.o[1] = A.pts[3 * mm + 1]; R.o[2] = A.pts[3 * mm + 2]; R.z = 0.f; R.d[0] = R.d[1] = R.d[2] = 0.f; return; }
-    const int n = mm / A.S;
+    const int n = ray_of(A, mm);     // = mm / A.S
     R.z = A.z[mm];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { R.o[k] = A.rays_o[3 * n + k]; R.d[k] = A.rays_d[3 * n + k]; }
@@ -1300,7 +1306,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         float px, py, pz;
         sample_finish(A, nx.r, px, py, pz);
         const float zz = A.pts ? 0.f : nx.r.z;
-        const int n = A.pts ? 0 : mm / A.S;
+        const int n = A.pts ? 0 : ray_of(A, mm);
         Tri T;
         tri_setup(A.grid, A.bound, px, py, pz, T);
         float gout[OD];

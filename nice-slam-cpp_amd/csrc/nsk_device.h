@@ -172,8 +172,21 @@ __global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int 
     const float gt = has_gt ? gt_depth[nc] : 0.f;
     float gmax = gtmax_dev ? *gtmax_dev : gtmax_host;
     if (has_gt && !gtmax_dev && gtmax_host < 0.f) {         // batch maximum computed by every wave itself (small batches: one launch fewer)
-        float mx = keep ? 0.f : -NSK_INF;                   // (see k_depth_max)
-        for (int i = lane; i < N; i += 64) if (!keep || keep[i]) mx = fmaxf(mx, gt_depth[i]);
+        // (four independent (depth, keep) load pairs per round: written as `if (keep[i]) mx = max(mx, gt[i])` the loop was two dependent
+        // L2 round trips per 64 rays -- half of this kernel's 19 us at 5000 rays)
+        const float mx0 = keep ? 0.f : -NSK_INF;            // (see k_depth_max)
+        float mx = mx0;
+        for (int i0 = 0; i0 < N; i0 += 256) {
+            float v[4]; uint8_t kp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 64 * u + lane, N - 1);          // (clamped: a repeated element does not change a maximum)
+                v[u] = gt_depth[i];
+                kp[u] = keep ? keep[i] : (uint8_t)1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, kp[u] ? v[u] : mx0);
+        }
         gmax = wave_max(mx);
     }
     const float ox = rays_o[3 * nc], oy = rays_o[3 * nc + 1], oz = rays_o[3 * nc + 2];
@@ -579,9 +592,10 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, int g, f4
     acc[1] = *reinterpret_cast<const f4*>(b + 16 + 4 * g);
 }
 
-// ReLU in place, returns the 8 "input was > 0" bits (bit r*4+i).  max(x, 0) is >= +0, so its bit pattern as an unsigned integer is
-// zero exactly when the ReLU's derivative is (x <= 0, or NaN -- v_max_f32 returns the other operand): min(bits, 1) is the bit.
-// Three vector instructions per element and no compare (a v_cmp feeding v_cndmask also costs wait states); NaN inputs become 0.
+// ReLU in place, returns the 8 "input was > 0" bits (bit r*4+i).  All in integer arithmetic on the bit patterns, three vector
+// instructions per element: max_i32(bits, 0) is the ReLU (negative floats, -0 and negative NaNs are negative integers), and the result
+// is a non-negative integer that is zero exactly when the ReLU's derivative is, so min_u32(result, 1) is the bit.  (The float form,
+// fmaxf + a compare, costs a canonicalising v_max on MFMA outputs, a v_cmp, a v_cndmask and wait states between them.)
 __device__ __forceinline__ uint32_t relu_mask(f4 (&a)[2])
 {
     uint32_t m = 0;
@@ -589,9 +603,9 @@ __device__ __forceinline__ uint32_t relu_mask(f4 (&a)[2])
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float y = fmaxf(a[r][i], 0.f);
-            a[r][i] = y;
-            m |= min(__float_as_uint(y), 1u) << (r * 4 + i);
+            const int y = max(__float_as_int(a[r][i]), 0);
+            a[r][i] = __int_as_float(y);
+            m |= min((unsigned)y, 1u) << (r * 4 + i);
         }
     return m;
 }

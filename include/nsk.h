@@ -61,10 +61,17 @@ int nsk_ctx_destroy(nsk_ctx* ctx);
 int nsk_sync(nsk_ctx* ctx);                         /* hipStreamSynchronize */
 void* nsk_stream(nsk_ctx* ctx);                     /* the hipStream_t in use */
 
-/* How the decoders' matrix products are evaluated (results agree to fp32 rounding):
- *   1 = fp32 operands split into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation (DEFAULT;
- *       forward of the MLP decoders in multi-decoder stages and the frozen decoders' backward chain without ray gradients);
- *   0 = v_mfma_f32_16x16x4_f32, plain fp32, everywhere.
+/* How the MLP decoders' FORWARD matrix products are evaluated (results agree within the 1e-4 contract; measured against the fp64
+ * oracle all three are equally close, tests/test_gpu_parity.py::test_forward_bf16_split_mode_matches_oracle):
+ *   2 = fp32 operands split into two fp16 pieces (x = h + l/2048: 22 significant bits), three v_mfma_f32_16x16x32_f16 per K=32
+ *       block, fp32 accumulation (DEFAULT).  Operand range: |x| < 65504 (fp16) for activations, grid features and weights -- far
+ *       above anything these decoders produce; larger values come out as inf / NaN in the rendering, never silently wrong;
+ *   1 = three bf16 pieces (24 significant bits, the full fp32 exponent range), six v_mfma_f32_16x16x32_bf16 per block;
+ *   0 = v_mfma_f32_16x16x4_f32, plain fp32.
+ * Independent of the mode: the frozen decoders' backward chain (without ray gradients) runs on two fp16 pieces of a per-sample
+ * power-of-two multiple of the upstream gradient (exact scaling: no range restriction); the trainable decoder's chain and every
+ * chain that carries ray gradients on the fp32 MFMA; the weight-gradient panels on two bf16 pieces with fp32 sums.
+ * Changing the mode rebuilds the forward images of the loaded decoders and invalidates captured graphs.
  * The library reads no environment variables: this call and nsk_set_render_opts are the only behaviour switches. */
 int nsk_set_matmul_mode(nsk_ctx* ctx, int mode);
 
@@ -81,7 +88,9 @@ int nsk_set_sort_mode(nsk_ctx* ctx, int mode);
  *                      contributions strictly one after the other (orders of magnitude slower; the trainable decoder's pose gradients are
  *                      not covered);
  *   "roctx" 1:         roctxRangePush/Pop around every launch group (names as in nsk_profile_end) for rocprofv3 --marker-trace;
- *   "frozen_cost" n:   relative cost of a frozen decoder's tile in the backward's workgroup split (0 = built-in value). */
+ *   "frozen_cost" n:   relative cost of a frozen decoder's tile in the backward's workgroup split (0 = built-in value);
+ *   "no_fused_median" 1: nsk_track_step computes the Tracker's median threshold in a launch of its own (composite, median, composite)
+ *                      even where the one-launch form applies. */
 int nsk_set_tuning(nsk_ctx* ctx, const char* key, int value);
 
 /* Scene bound [[x0,x1],[y0,y1],[z0,z1]]; the reference hard-codes it in five places
@@ -173,7 +182,10 @@ int nsk_map_step(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const fl
 
 /* One tracking iteration without the Adam step (src/Tracker.cpp:41-89): render, dynamic-outlier mask
  * |gt_d - d| < 10 median (:67-71), loss sum_mask |gt_d - d| / sqrt(var + 1e-10) + w_color sum_mask |gt_c - c|
- * (:75-82), backward onto the rays.  detach_var: treat depth_var as a constant. */
+ * (:75-82), backward onto the rays.  detach_var: treat depth_var as a constant.
+ * With handle_dynamic and at most 1024 rays (and at most one 4-ray workgroup per CU) the median is found inside the loss launch:
+ * the residuals meet at a device-wide barrier whose wait is bounded; should it ever time out, that step ran with an infinite
+ * threshold and the next nsk_sync returns the error. */
 int nsk_track_step(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d,
                    const float* d_gt_depth, const float* d_gt_color, float gt_depth_max, float w_color, int use_color,
                    int handle_dynamic, int detach_var, unsigned flags, float* d_loss, float* d_g_rays_o,

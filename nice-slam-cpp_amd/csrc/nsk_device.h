@@ -605,7 +605,11 @@ __device__ __forceinline__ uint32_t relu_mask(f4 (&a)[2])
         for (int i = 0; i < 4; ++i) {
             const int y = max(__float_as_int(a[r][i]), 0);
             a[r][i] = __int_as_float(y);
-            m |= min((unsigned)y, 1u) << (r * 4 + i);
+            // m |= min(y, 1) << bit, as exactly two instructions (left to itself the compiler turns the min into a compare and a select,
+            // 3.5 instructions per element; their input is the v_max_i32 above, a vector-ALU result: no matrix-pipe hazard inside the asm)
+            unsigned t;
+            asm("v_min_u32 %0, %1, 1" : "=v"(t) : "v"(y));
+            asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(m) : "v"(t), "n"(r * 4 + i), "v"(m));
         }
     return m;
 }

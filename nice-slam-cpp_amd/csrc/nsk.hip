@@ -1430,7 +1430,7 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     A.g_rays_o = g_ro; A.g_rays_d = g_rd;
     A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
     A.flags = flags;
-    if (w != 0 && !train && !rays) CHK(ensure_bimg16(c, w));      // the frozen chain on fp16 pieces
+    if (w != 0 && (train ? w != 2 : !rays)) CHK(ensure_bimg16(c, w));      // the chains on fp16 pieces: frozen without ray gradients, trainable middle / colour
     if (train && w != 2) {
         if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
         A.hsave = c->ws.hsave[w];
@@ -1787,7 +1787,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
 #else
         A.flags = flags & 0xffu;
 #endif
-        if (w != 0 && !train && !rays) CHK(ensure_bimg16(c, w));
+        if (w != 0 && (train ? w != 2 : !rays)) CHK(ensure_bimg16(c, w));
         if (train && w != 2) {
             if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
             A.hsave = c->ws.hsave[w];

@@ -220,14 +220,15 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     // (nsk_device.h: MlpBwdImgH, chain_scale) instead of 240 fp32 MFMAs per tile; the image has the size of the fp32 one.
     // Built, parity-green and OFF: 90 MFMAs of 16 cycles replace 240 of 32, and the iteration did not get shorter (K3: 27.7 against
     // 27.1 us per 128 samples, 59 spilled VGPRs) -- the role waits on its panel phases, not on issue slots.
-    constexpr bool H16 = false && XYZ && SAVED;
+    constexpr bool H16 = XYZ && SAVED;
     typedef MlpFwdImg<CQ> FI;
     typedef TrainPlan<WHICH> PL;
     constexpr PL plan{};
     constexpr int BWD_F = XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL;
     constexpr int IMG_F = SAVED ? BWD_F : 0;
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
+    int lane = lane0, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     char* pn = reinterpret_cast<char*>(smf + IMG_F);     // shared panel (plane H; plane M at + PM)
     constexpr int PM = PN_MOFF(CQ);
@@ -289,6 +290,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     if constexpr (SAVED) asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
+        // the lane index is made opaque once per iteration: per-lane LDS addresses (panel rows of every phase, fragment rows) are then
+        // rebuilt from it with immediate offsets instead of being hoisted out of the loop, where ~50 of them were spilled to scratch
+        // (and every reload inside the loop is a vmcnt wait behind the previous iteration's atomics)
+        lane = lane0; asm volatile("" : "+v"(lane)); j = lane & 15; g = lane >> 4;
         NSK_PH(0); NSK_PHI(0);
         if (it > 0) lds_barrier();                   // the head of the panel was the waves' scatter scratch until here
         const bool valid = nx.valid;
@@ -350,6 +355,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
         f4 ge[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
+        H2 xa3;
         auto load_h = [&](auto KC) {
             constexpr int k = decltype(KC)::value;
             const f4* src = A.hsave + ((size_t)htask * 10 + 2 * k) * 64 + lane;
@@ -438,9 +444,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
             }
             if constexpr (l == 3) NSK_PH(15); NSK_PHI(15);
             if constexpr (H16) {
-                if constexpr (l == 3) gemm_e_h(imgh, MlpBwdImgH::W3ET, lane, xa, ge);
-                if constexpr (l == 3) NSK_PH(16); NSK_PHI(16);
-                if constexpr (l == 0) gemm_e_h(imgh, MlpBwdImgH::W0ET, lane, xa, ge);
+                // g_e = W3e^T g_a3 + W0e^T g_a0 is needed only after the chain: layer 3 keeps the pieces of g_a3 (8 registers) instead of
+                // forming its share of g_e (24 registers) three layers early
+                if constexpr (l == 3) xa3 = xa;
+                if constexpr (l == 0) { gemm_e_h(imgh, MlpBwdImgH::W3ET, lane, xa3, ge); gemm_e_h(imgh, MlpBwdImgH::W0ET, lane, xa, ge); }
                 if constexpr (l >= 1) {
                     f4 ghn[2] = {(f4)(0.f), (f4)(0.f)}, ghl[2] = {(f4)(0.f), (f4)(0.f)};
                     gemm_h(imgh, MlpBwdImgH::WT(l), lane, xa, ghn, ghl);

@@ -363,9 +363,9 @@ def main():
                    "id": args.workload, "rays_per_gpu": N, "samples_per_ray": 48, "stage": args.stage,
                    "grid_shapes": {k: list(v.shape) for k, v in res["sc"]["grids"].items()},
                    "matmul": "fp32 operands as 16-bit pieces on the matrix cores with fp32 accumulation: forward = two fp16 pieces (22 significant bits, "
-                             "3 MFMAs per K=32 block); frozen decoders' backward chains = two fp16 pieces of a per-sample power-of-two multiple of the "
-                             "gradient; the trainable decoder's weight-gradient panels = two bf16 pieces (16 bits, fp32 sums); fp32 MFMA for the "
-                             "trainable decoder's chain and the grid-gradient scatter",
+                             "3 MFMAs per K=32 block); backward chains (frozen and trainable decoders) = two fp16 pieces of a per-sample power-of-two "
+                             "multiple of the gradient; the trainable decoder's weight-gradient panels = two bf16 pieces (16 bits, fp32 sums); fp32 MFMA "
+                             "for the grid-gradient scatter",
                    "frustum_feature_selection": res["mask_frac"] is not None, "marked_voxel_fraction": res["mask_frac"],
                    "parallelism": "rays sharded x%d, 1 all-reduce/step of %d floats (%.2f MB: marked voxels of the trained levels + colour decoder + loss; "
                                   "the dense gradient slab is %d floats)" % (world, res["exchange_floats"], 4e-6 * res["exchange_floats"], res["slab_floats"])},

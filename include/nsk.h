@@ -68,9 +68,10 @@ void* nsk_stream(nsk_ctx* ctx);                     /* the hipStream_t in use */
  *       above anything these decoders produce; larger values come out as inf / NaN in the rendering, never silently wrong;
  *   1 = three bf16 pieces (24 significant bits, the full fp32 exponent range), six v_mfma_f32_16x16x32_bf16 per block;
  *   0 = v_mfma_f32_16x16x4_f32, plain fp32.
- * Independent of the mode: the frozen decoders' backward chain (without ray gradients) runs on two fp16 pieces of a per-sample
- * power-of-two multiple of the upstream gradient (exact scaling: no range restriction); the trainable decoder's chain and every
- * chain that carries ray gradients on the fp32 MFMA; the weight-gradient panels on two bf16 pieces with fp32 sums.
+ * Independent of the mode: the backward chains of the frozen decoders (without ray gradients) and of a trainable middle / colour
+ * decoder run on two fp16 pieces of a per-sample power-of-two multiple of the upstream gradient (exact scaling: no range
+ * restriction); frozen chains that carry ray gradients, the coarse decoder and a trainable fine decoder on the fp32 MFMA; the
+ * weight-gradient panels on two bf16 pieces with fp32 sums.
  * Changing the mode rebuilds the forward images of the loaded decoders and invalidates captured graphs.
  * The library reads no environment variables: this call and nsk_set_render_opts are the only behaviour switches. */
 int nsk_set_matmul_mode(nsk_ctx* ctx, int mode);

@@ -218,8 +218,10 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     constexpr bool SAVED = WHICH != 2;
     // H16: the chain's transposed products (g_c, g_h, g_e) on the fp16 matrix cores with 2-piece operands and a per-sample scale
     // (nsk_device.h: MlpBwdImgH, chain_scale) instead of 240 fp32 MFMAs per tile; the image has the size of the fp32 one.
-    // Built, parity-green and OFF: 90 MFMAs of 16 cycles replace 240 of 32, and the iteration did not get shorter (K3: 27.7 against
-    // 27.1 us per 128 samples, 59 spilled VGPRs) -- the role waits on its panel phases, not on issue slots.
+    // 90 MFMAs of 16 cycles replace 240 of 32.  First built, it did not shorten the iteration (K3: 27.7 against 27.1 us per 128
+    // samples) because it spilled 59 VGPRs -- loop-invariant per-lane addresses, reloaded from scratch inside the loop, each reload
+    // a vmcnt wait behind the previous iteration's atomics.  Without spills (opaque lane index per iteration, g_e formed after the
+    // chain): 24 us, backward 270 -> 240 us at K3.
     constexpr bool H16 = XYZ && SAVED;
     typedef MlpFwdImg<CQ> FI;
     typedef TrainPlan<WHICH> PL;

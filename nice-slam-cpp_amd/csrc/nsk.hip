@@ -809,6 +809,7 @@ static size_t bwd_lds_bytes(int w, bool train)
 {
     size_t scratch = 8 * 3840;                               // 8 waves x (NSK_SCRATCH_FLOATS <= 960) floats
     if (!train) return bwd_img_floats(w) * 4 + scratch;
+    if (w == 1 || w == 3) return PM_LDS_BYTES;               // merged-phase body (nsk_train.h): 18 fragment groups + tail + 224 panel rows
     size_t img = w == 2 ? 0 : bwd_img_floats(w);          // saved-activation form: only the backward image sits in LDS
     return (img + PN_FLOATS(w == 2 ? 4 : 2)) * 4;            // the per-wave scatter scratch lives in panel rows 0..63
 }

@@ -127,7 +127,8 @@ __device__ __forceinline__ void pn_put(char* __restrict__ pn, int moff, int row0
 
 // the tiles of one phase owned by this wave, accumulated over the panel's 128 samples
 template <int NSL>
-__device__ __forceinline__ void pn_tiles(const char* __restrict__ pn, int moff, int RT, int NC, int rowsum, int wave, int lane, f4* acc, int xrow0 = PN_GROWS)
+__device__ __forceinline__ void pn_tiles(const char* __restrict__ pn, int moff, int RT, int NC, int rowsum, int wave, int lane, f4* acc, int xrow0 = PN_GROWS,
+                                         int grow0 = 0)
 {
     const int r = lane & 15, sq = lane >> 4;
     const int ntiles = RT * NC + (rowsum ? RT : 0);
@@ -138,7 +139,7 @@ __device__ __forceinline__ void pn_tiles(const char* __restrict__ pn, int moff, 
             const bool rs = tile >= RT * NC;
             const int rt = rs ? tile - RT * NC : tile / NC;
             const int ch = rs ? 0 : tile % NC;
-            const char* ga = pn + (16 * rt + r) * PN_RB + 16 * sq;
+            const char* ga = pn + (grow0 + 16 * rt + r) * PN_RB + 16 * sq;
             const char* xb = pn + (xrow0 + 16 * ch + r) * PN_RB + 16 * sq;
             f4 d0 = acc[k], d1 = (f4)(0.f);
 #pragma unroll
@@ -583,8 +584,299 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     NSK_PH(12);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Trainable middle / colour decoder, ONE panel phase per layer (round 2).  decode_bwd_train_body above spends 26 barriers per
+// iteration on 13 phases; here the two weight phases of a layer (dFc_l = g_h c^T and dW_l = g_a x^T) share one store -> barrier ->
+// tiles -> barrier sequence, and the grid features c are stored once per iteration.  That needs g_h, g_a, c and the layer input in
+// the panel at the same time (128 rows + 96 rows of e = 224 rows, 121 856 B); the room comes from the e-part fragments
+// (W0e^T, W3e^T: 24 KB), which g_e's two products -- both after the chain now -- read from global memory (L2) instead of LDS.
+//   rows   0..31  G1: g_h (phase OUT: g_out; phase DB: p)         rows  64..95  XC: c (written once per iteration)
+//   rows  32..63  G2: g_a                                          rows  96..127 XH: layer input h_{l-1} (phase OUT: h4)
+//   rows 128..223 E : sin(pB), later g_s                           (the per-wave scatter scratch is plane H of rows 0..124)
+// LDS image: fragment groups 0..17 of MlpBwdImgH (fc^T, W^T h parts) | Wo | B.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define PM_G1 0
+#define PM_G2 32
+#define PM_XC 64
+#define PM_XH 96
+#define PM_E 128
+#define PM_ROWS 224
+#define PM_IMG_FRAG_F (18 * 2 * 1024 / 4)               // floats of the LDS-resident fragment groups
+#define PM_IMG_F (PM_IMG_FRAG_F + 128 + 288)            // + Wo + B
+#define PM_LDS_BYTES (PM_IMG_F * 4 + PM_ROWS * PN_RB * 2)
+
+// acc[0..5] += W?e^T x with the fragments read from global memory, one 32-row slice (4 fragment loads) at a time
+__device__ __forceinline__ void gemm_e2_global(const h8* __restrict__ gimg, int lane, const H2& x3, const H2& x0, f4 (&acc)[6])
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const FragH a30 = load_frag_h(gimg, MlpBwdImgH::W3ET + 2 * a, lane), a31 = load_frag_h(gimg, MlpBwdImgH::W3ET + 2 * a + 1, lane);
+        const FragH a00 = load_frag_h(gimg, MlpBwdImgH::W0ET + 2 * a, lane), a01 = load_frag_h(gimg, MlpBwdImgH::W0ET + 2 * a + 1, lane);
+        f4 tH[2] = {acc[2 * a], acc[2 * a + 1]}, tL[2] = {(f4)(0.f), (f4)(0.f)};
+        mac_block_h(a30, a31, x3, tH, tL);
+        mac_block_h(a00, a01, x0, tH, tL);
+        acc[2 * a] = tH[0] + tL[0] * (1.f / NSK_H16_SCALE); acc[2 * a + 1] = tH[1] + tL[1] * (1.f / NSK_H16_SCALE);
+    }
+}
+
 template <int WHICH, bool RAYS>
-__global__ __launch_bounds__(512) void k_decode_bwd_train(DecArgs A) { decode_bwd_train_body<WHICH, RAYS>(A, blockIdx.x, gridDim.x); }
+__device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bid, int nb)
+{
+    static_assert(WHICH == 1 || WHICH == 3, "merged-phase body: middle and colour decoders");
+    constexpr int CQ = 2;
+    constexpr int OD = WHICH == 3 ? 4 : 1;
+    typedef TrainPlan<WHICH> PL;
+    constexpr PL plan{};
+    extern __shared__ __attribute__((aligned(16))) f4 smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
+    int lane = lane0, j = lane & 15, g = lane >> 4;
+    float* smf = reinterpret_cast<float*>(smem);
+    char* pn = reinterpret_cast<char*>(smf + PM_IMG_F);
+    constexpr int PM = PM_ROWS * PN_RB;                  // plane M behind plane H
+    float* scratch = smf + PM_IMG_F + wave * 1056;       // per-wave scatter scratch: plane H of rows 0..124 (G1, G2, XC, XH), all rewritten only after the next iteration's first barrier
+    static_assert(8 * 1056 * 4 <= PM_E * PN_RB, "scatter scratch must end before the E rows");
+    {
+        const f4* src = reinterpret_cast<const f4*>(A.bimg16);
+        copy_image_to_lds<512>(smem, src, PM_IMG_FRAG_F / 4);
+        copy_image_to_lds<512>(smem + PM_IMG_FRAG_F / 4, src + MlpBwdImgH::P_WO / 4, (128 + 288) / 4);
+    }
+    __syncthreads();
+    const h8* imgh = reinterpret_cast<const h8*>(smem);
+    const h8* gimg = reinterpret_cast<const h8*>(A.bimg16);          // e-part fragments stay in global memory
+    const float* Wo = smf + PM_IMG_FRAG_F;
+    const float* Bm = Wo + 128;
+
+    f4 acc[plan.nslots];
+#pragma unroll
+    for (int k = 0; k < plan.nslots; ++k) acc[k] = (f4)(0.f);
+
+    const int ntasks = (A.M + 15) >> 4;
+    const int iters = tiles_per_wave(ntasks, nb * 8, 0);
+    const bool scat = (A.flags & 1u) && A.grid.g;
+    struct Staged { float px, py, pz, zz; int n; bool valid; f4 gr; f4 xc[CQ]; f4 h4[2]; unsigned long long mask; } nx;
+    auto task_of = [&](int it_) { return tile_of(it_, bid * 8 + wave, nb * 8, 0); };
+    auto slot_of = [&](int it_) { return task_of(it_) * 16 + j; };
+    auto stage_a = [&](int it_, int mm, Staged& S_) {
+        const int task = task_of(it_);
+        const int slot = task * 16 + j;
+        S_.valid = slot < A.M;
+        sample_point(A, mm, S_.px, S_.py, S_.pz, S_.zz, S_.n);
+        S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+        const int tk = min(task, ntasks - 1);
+        S_.mask = A.masks[(size_t)min(slot, A.M - 1) * 4 + g];
+        S_.h4[0] = A.hsave[((size_t)tk * 10 + 8) * 64 + lane]; S_.h4[1] = A.hsave[((size_t)tk * 10 + 9) * 64 + lane];
+    };
+    auto stage_b = [&](Staged& S_) {
+        Tri T_;
+        tri_setup(A.grid, A.bound, S_.px, S_.py, S_.pz, T_);
+        tri_gather(A.grid, T_, g, S_.xc[0], S_.xc[1]);
+    };
+    int mm_next = 0;
+    if (iters > 0) { stage_a(0, slot_sample(A, slot_of(0)), nx); stage_b(nx); mm_next = slot_sample(A, slot_of(1)); }
+    asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" ::: "memory");
+        lane = lane0; asm volatile("" : "+v"(lane)); j = lane & 15; g = lane >> 4;      // (see decode_bwd_train_body)
+        if (it > 0) lds_barrier();                   // scratch (G1 / G2), XC and E are rewritten from here on
+        const bool valid = nx.valid;
+        float px = nx.px, py = nx.py, pz = nx.pz, zz = nx.zz; const int n = nx.n;
+        float gout[OD];
+        {
+            f4 gr = nx.gr;
+            if (!valid) gr = (f4)(0.f);
+            if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
+            else gout[0] = gr[3];
+        }
+        f4 go;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) go[i] = (4 * g + i) < OD ? gout[(4 * g + i) < OD ? (4 * g + i) : 0] : 0.f;
+        const float us = chain_scale<OD>(gout);
+        const unsigned long long mask = nx.mask;
+        const int htask = min(task_of(it), ntasks - 1);
+        f4 hq[5][2];                                      // block outputs h0..h4 as they are fetched
+        hq[4][0] = nx.h4[0]; hq[4][1] = nx.h4[1];
+        auto load_h = [&](auto KC) {
+            constexpr int k = decltype(KC)::value;
+            const f4* src = A.hsave + ((size_t)htask * 10 + 2 * k) * 64 + lane;
+            hq[k][0] = src[0]; hq[k][1] = src[64];
+        };
+        load_h(std::integral_constant<int, 3>{});
+        {
+            f4 xe[6], dummy[6];
+            embed<false>(Bm, g, px, py, pz, xe, dummy);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) pn_put(pn, PM, PM_E + 16 * q, wave, lane, xe[q]);
+        }
+        pn_put(pn, PM, PM_XC, wave, lane, nx.xc[0]);
+        pn_put(pn, PM, PM_XC + 16, wave, lane, nx.xc[1]);
+        f4 gh[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < OD; ++o) s += Wo[32 * o + 16 * r + 4 * g + i] * gout[o];
+                gh[r][i] = s;
+            }
+        // ---- phase OUT: G = g_out (rows >= OD zero), X = h4 --------------------------------------------------------------------
+        {
+            pn_put(pn, PM, PM_G1, wave, lane, go);
+            pn_put(pn, PM, PM_XH, wave, lane, hq[4][0]);
+            pn_put(pn, PM, PM_XH + 16, wave, lane, hq[4][1]);
+            lds_barrier();
+            constexpr TrainPhase P = plan.p[PL::P_OUT];
+            pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PM_XH, PM_G1);
+            lds_barrier();
+        }
+        f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
+        H2 xa3, xa;
+        auto layer = [&](auto LC) {
+            constexpr int l = decltype(LC)::value;
+            if constexpr (l >= 2) load_h(std::integral_constant<int, l - 2>{});      // a whole layer ahead (see decode_bwd_train_body)
+            {
+                const H2 xg = split_block_h(gh[0], gh[1]);
+                f4 gl[2] = {(f4)(0.f), (f4)(0.f)};
+                gemm_h(imgh, MlpBwdImgH::FT(l), lane, xg, gc, gl);               // g_c += fc[l]^T g_h
+                gc[0] += gl[0] * (1.f / NSK_H16_SCALE); gc[1] += gl[1] * (1.f / NSK_H16_SCALE);
+            }
+            f4 ga[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
+            xa = split_block_h(ga[0], ga[1]);
+            // ---- the layer's phase: dFc_l = g_h c^T (G1 x XC), dW_l = g_a x^T (G2 x XH or E) ------------------------------------
+            pn_put(pn, PM, PM_G1, wave, lane, gh[0], us);
+            pn_put(pn, PM, PM_G1 + 16, wave, lane, gh[1], us);
+            pn_put(pn, PM, PM_G2, wave, lane, ga[0], us);
+            pn_put(pn, PM, PM_G2 + 16, wave, lane, ga[1], us);
+            if constexpr (l >= 1) {
+                constexpr int k = l == 3 ? 2 : l - 1;                            // layer 3 reads e (its own rows) and h2
+                pn_put(pn, PM, PM_XH, wave, lane, hq[k][0]);
+                pn_put(pn, PM, PM_XH + 16, wave, lane, hq[k][1]);
+            }
+            lds_barrier();
+            {
+                // FC tiles: six per layer.  In the layers whose W phase has fourteen tiles (0, 3) they are dealt to waves 6, 7, 0..3 so that no
+                // wave gets more than three (W: waves 0..5 two, 6..7 one; W3H: waves 4..7)
+                constexpr TrainPhase PF = plan.p[PL::P_FC0 + l];
+                constexpr int rot = (l == 0 || l == 3) ? 2 : 0;
+                pn_tiles<PF.nslots>(pn, PM, PF.RT, PF.NC, PF.rowsum, (wave + rot) & 7, lane, acc + PF.slot0, PM_XC, PM_G1);
+                constexpr TrainPhase PW = plan.p[PL::P_W0 + l];
+                pn_tiles<PW.nslots>(pn, PM, PW.RT, PW.NC, PW.rowsum, wave, lane, acc + PW.slot0, (l == 0 || l == 3) ? PM_E : PM_XH, PM_G2);
+                if constexpr (l == 3) {
+                    constexpr TrainPhase P2 = plan.p[PL::P_W3H];
+                    pn_tiles<P2.nslots>(pn, PM, P2.RT, P2.NC, P2.rowsum, (wave + 4) & 7, lane, acc + P2.slot0, PM_XH, PM_G2);
+                }
+            }
+            lds_barrier();
+            if constexpr (l == 3) xa3 = xa;
+            if constexpr (l >= 1) {
+                f4 ghn[2] = {(f4)(0.f), (f4)(0.f)}, ghl[2] = {(f4)(0.f), (f4)(0.f)};
+                gemm_h(imgh, MlpBwdImgH::WT(l), lane, xa, ghn, ghl);
+                gh[0] = ghn[0] + ghl[0] * (1.f / NSK_H16_SCALE); gh[1] = ghn[1] + ghl[1] * (1.f / NSK_H16_SCALE);
+            }
+        };
+        layer(std::integral_constant<int, 4>{});
+        layer(std::integral_constant<int, 3>{});
+        layer(std::integral_constant<int, 2>{});
+        layer(std::integral_constant<int, 1>{});
+        layer(std::integral_constant<int, 0>{});
+        f4 ge[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
+        gemm_e2_global(gimg, lane, xa3, xa, ge);            // g_e = W3e^T g_a3 + W0e^T g_a0 (still carries the sample's scale)
+        if (it + 1 < iters) { stage_a(it + 1, mm_next, nx); mm_next = slot_sample(A, slot_of(it + 2)); }
+        gc[0] *= us; gc[1] *= us;
+        float gp[3] = {0.f, 0.f, 0.f};
+        Tri T;
+        tri_setup(A.grid, A.bound, px, py, pz, T);
+        {
+            f4 e2[6], xcos[6];
+            embed<true>(Bm, g, px, py, pz, e2, xcos);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ge[q] *= xcos[q];
+        }
+        // ---- phase DB: G = p (3 rows, times the unscale factor), X = g_s -----------------------------------------------------------
+        {
+            f4 pq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
+            pn_put(pn, PM, PM_G1, wave, lane, pq, us);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) pn_put(pn, PM, PM_E + 16 * q, wave, lane, ge[q]);
+            lds_barrier();
+            constexpr TrainPhase P = plan.p[PL::P_DB];
+            pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PM_E, PM_G1);
+            lds_barrier();
+        }
+        if constexpr (RAYS) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                f4 b0 = *reinterpret_cast<const f4*>(Bm + 16 * q + 4 * g);
+                f4 b1 = *reinterpret_cast<const f4*>(Bm + 96 + 16 * q + 4 * g);
+                f4 b2 = *reinterpret_cast<const f4*>(Bm + 192 + 16 * q + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { gp[0] += ge[q][i] * b0[i]; gp[1] += ge[q][i] * b1[i]; gp[2] += ge[q][i] * b2[i]; }
+            }
+            gp[0] *= us; gp[1] *= us; gp[2] *= us;
+            tri_grad_p(A.grid, T, g, gc, gp);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gp[k] += __shfl_xor(gp[k], 16); gp[k] += __shfl_xor(gp[k], 32); }
+            if (A.g_rays_o) {
+                const int n0 = __builtin_amdgcn_readfirstlane(n);
+                if (__builtin_amdgcn_ballot_w64(valid && n != n0) == 0ull) {
+                    float a[6];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { a[k] = valid ? gp[k] : 0.f; a[3 + k] = valid ? gp[k] * zz : 0.f; }
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) a[k] += __shfl_xor(a[k], o);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { atomicAdd(A.g_rays_o + 3 * n0 + k, a[k]); atomicAdd(A.g_rays_d + 3 * n0 + k, a[3 + k]); }
+                    }
+                } else if (g == 0 && valid) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        atomicAdd(A.g_rays_o + 3 * n + k, gp[k]);
+                        atomicAdd(A.g_rays_d + 3 * n + k, gp[k] * zz);
+                    }
+                }
+            }
+        }
+        if (it + 1 < iters) stage_b(nx);
+        // every staged load must have landed before the first atomic below (see decode_bwd_train_body)
+        asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
+        if (scat) {
+            if (A.flags & 0x8000u) {        // deterministic debug mode: see decode_bwd_body
+                for (int w = 0; w < 8; ++w) { if (wave == w) { scatter_tile(A.grid, T, gc, lane, valid, scratch); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } __syncthreads(); }
+            } else scatter_tile(A.grid, T, gc, lane, valid, scratch);
+        }
+    }
+    // ---- single flush of this wave's output tiles (the wave rotations of the tiles above) ---------------------------------------
+    float* slab = A.g_dec + (size_t)bid * ((plan_total<WHICH>() + 3) & ~3);
+#define NSK_FLUSHW(ID, W) if constexpr (plan.p[ID].nslots > 0) pn_flush<plan.p[ID].nslots>(slab, plan.p[ID], W, lane, acc + plan.p[ID].slot0);
+    NSK_FLUSHW(PL::P_OUT, wave)
+    NSK_FLUSHW(PL::P_FC0 + 0, (wave + 2) & 7) NSK_FLUSHW(PL::P_FC0 + 1, wave) NSK_FLUSHW(PL::P_FC0 + 2, wave) NSK_FLUSHW(PL::P_FC0 + 3, (wave + 2) & 7) NSK_FLUSHW(PL::P_FC0 + 4, wave)
+    NSK_FLUSHW(PL::P_W0 + 0, wave) NSK_FLUSHW(PL::P_W0 + 1, wave) NSK_FLUSHW(PL::P_W0 + 2, wave) NSK_FLUSHW(PL::P_W0 + 3, wave) NSK_FLUSHW(PL::P_W0 + 4, wave)
+    NSK_FLUSHW(PL::P_W3H, (wave + 4) & 7) NSK_FLUSHW(PL::P_DB, wave)
+#undef NSK_FLUSHW
+}
+
+// which body a trainable decoder's backward runs: the merged-phase form for the middle and colour decoders
+template <int WHICH, bool RAYS>
+__device__ __forceinline__ void decode_bwd_train_any(const DecArgs& A, int bid, int nb)
+{
+    if constexpr (WHICH == 1 || WHICH == 3) decode_bwd_train_m_body<WHICH, RAYS>(A, bid, nb);
+    else decode_bwd_train_body<WHICH, RAYS>(A, bid, nb);
+}
+
+template <int WHICH, bool RAYS>
+__global__ __launch_bounds__(512) void k_decode_bwd_train(DecArgs A) { decode_bwd_train_any<WHICH, RAYS>(A, blockIdx.x, gridDim.x); }
 
 // one launch for the backward of all decoders of a stage (roles as in k_decode_fwd_multi; train[r] selects the
 // trainable-decoder body, whose workgroups synchronise only among themselves)
@@ -600,13 +892,13 @@ __global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
     const int sel = MA.which[r] * 2 + (MA.train[r] ? 1 : 0);
     switch (sel) {
     case 0: decode_bwd_body<0, RAYS>(MA.a[r], bid, nb); break;
-    case 1: decode_bwd_train_body<0, RAYS>(MA.a[r], bid, nb); break;
+    case 1: decode_bwd_train_any<0, RAYS>(MA.a[r], bid, nb); break;
     case 2: decode_bwd_body<1, RAYS>(MA.a[r], bid, nb); break;
-    case 3: decode_bwd_train_body<1, RAYS>(MA.a[r], bid, nb); break;
+    case 3: decode_bwd_train_any<1, RAYS>(MA.a[r], bid, nb); break;
     case 4: decode_bwd_body<2, RAYS>(MA.a[r], bid, nb); break;
     case 5: break;     // trainable fine decoder (64-wide c: 1.4 KB of scratch per lane): launched on its own as k_decode_bwd_train<2>, never here
     case 6: decode_bwd_body<3, RAYS>(MA.a[r], bid, nb); break;
-    default: decode_bwd_train_body<3, RAYS>(MA.a[r], bid, nb); break;
+    default: decode_bwd_train_any<3, RAYS>(MA.a[r], bid, nb); break;
     }
     NSK_TS_END(1, r);
 }

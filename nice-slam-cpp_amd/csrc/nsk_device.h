@@ -405,24 +405,6 @@ __device__ __forceinline__ B3 split_block(f4 q0, f4 q1)
     return r;
 }
 
-// the pieces of (bit ? x : 0) from the pieces of x: the ReLU backward masks a gradient the chain has just split for the fc[l]^T product,
-// and the pieces of a zero are zeros, so twelve ANDs replace a second split (44 vector instructions per layer in the frozen roles).
-// bits: bit j <-> element j of the block.
-__device__ __forceinline__ B3 mask_block(const B3& x, unsigned bits)
-{
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    u4 h = __builtin_bit_cast(u4, x.h), m = __builtin_bit_cast(u4, x.m), l = __builtin_bit_cast(u4, x.l);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const unsigned lo = 0u - ((bits >> (2 * d)) & 1u), hi = 0u - ((bits >> (2 * d + 1)) & 1u);
-        const unsigned k = (lo & 0xffffu) | (hi & 0xffff0000u);
-        h[d] &= k; m[d] &= k; l[d] &= k;
-    }
-    B3 r;
-    r.h = __builtin_bit_cast(bf8, h); r.m = __builtin_bit_cast(bf8, m); r.l = __builtin_bit_cast(bf8, l);
-    return r;
-}
-
 struct Frag3 { bf8 h, m, l; };
 __device__ __forceinline__ Frag3 load_frag(const bf8* __restrict__ img, int fg, int lane)
 {
@@ -476,7 +458,8 @@ __device__ __forceinline__ void mac_block_h(const FragH& a0, const FragH& a1, co
     accL[0] = mfma_h(a0.h, x.l, accL[0]); accL[1] = mfma_h(a1.h, x.l, accL[1]);
     accL[0] = mfma_h(a0.l, x.h, accL[0]); accL[1] = mfma_h(a1.l, x.h, accL[1]);
 }
-// the pieces of (bit ? x : 0) from the pieces of x (see mask_block): bit j <-> element j of the block
+// the pieces of (bit ? x : 0) from the pieces of x: the ReLU backward masks a gradient the chain has just split for the fc[l]^T product,
+// and the pieces of a zero are zeros, so eight ANDs replace a second split.  bits: bit j <-> element j of the block
 __device__ __forceinline__ H2 mask_block_h(const H2& x, unsigned bits)
 {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));

@@ -586,7 +586,8 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
 
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Trainable middle / colour decoder, ONE panel phase per layer (round 2).  decode_bwd_train_body above spends 26 barriers per
+// Trainable middle / colour decoder, ONE panel phase per layer (round 2; measured no faster than the two-phase form -- the iteration
+// is issue-bound, 21.7 us either way -- and no slower).  decode_bwd_train_body above spends 26 barriers per
 // iteration on 13 phases; here the two weight phases of a layer (dFc_l = g_h c^T and dW_l = g_a x^T) share one store -> barrier ->
 // tiles -> barrier sequence, and the grid features c are stored once per iteration.  That needs g_h, g_a, c and the layer input in
 // the panel at the same time (128 rows + 96 rows of e = 224 rows, 121 856 B); the room comes from the e-part fragments

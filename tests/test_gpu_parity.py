@@ -81,6 +81,52 @@ def test_backward_matches_golden(path):
         assert e < TOL, (k, e, errs)
 
 
+@pytest.mark.parametrize("stage,trainable", [("fine", []), ("color", ["color"])])
+def test_backward_chains_keep_relative_accuracy_across_decades(stage, trainable):
+    """The backward chains run on fp16 pieces of a per-sample power-of-two multiple of the upstream gradient (chain_scale).  Upstream
+    gradients that differ by sixty decades between rays -- 2^-100 ... 2^100, far outside fp16 in both directions -- must come out with
+    the accuracy of the unscaled run, ray group by ray group (the gradient is linear in the upstream gradient and the factors are powers
+    of two: apart from the order of the atomic sums the results are the unscaled ones times the factor), and a batch that mixes all the
+    scales must give the sum of the single-scale runs."""
+    sc = _scene(51, grid_std=0.3)
+    rays = scenes.make_rays(52, 48, sc["bound"], n_frames=2)
+    ro, rd, gd = cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"])
+    N = rays["rays_o"].shape[0]
+    rng = np.random.default_rng(9)
+    g_rgb = rng.standard_normal((N, 3)).astype(np.float32)
+    g_d = rng.standard_normal(N).astype(np.float32)
+    levels = stage_levels(stage)
+    groups = np.arange(N) % 4
+    expo = np.array([-100, -40, 0, 100])
+    flags = 3 if trainable else 1
+
+    def run(mult):
+        ctx = make_ctx(sc, trainable=trainable)
+        ctx.render_backward(stage, ro, rd, gd, -1.0, cu(g_rgb * mult[:, None]), cu(g_d * mult), None, flags=flags)
+        ctx.sync()
+        out = {k: ctx.grid_download(k, grad=True).astype(np.float64) for k in levels}
+        if trainable:
+            out["decoder"] = ctx.decoder_download("color", grad=True).astype(np.float64)
+        return out
+
+    total = None
+    for gi in range(4):
+        sel = (groups == gi).astype(np.float32)
+        base = run(sel)                                              # this group's rays alone, unscaled
+        assert all(np.abs(v).max() > 0 for v in base.values())
+        f = np.ldexp(np.float32(1), int(expo[gi]))
+        got = run(sel * f)
+        for k, v in got.items():
+            assert np.isfinite(v).all(), (k, expo[gi])
+            e = rel_l2(v / float(f), base[k])
+            assert e < 1e-5, "upstream gradient x 2^%d: %s differs from the unscaled run by %.2e" % (expo[gi], k, e)
+        total = {k: v.copy() for k, v in got.items()} if total is None else {k: total[k] + got[k] for k in got}
+    mixed = run(np.ldexp(np.float32(1), expo[groups]).astype(np.float32))
+    for k, v in mixed.items():
+        assert np.isfinite(v).all()
+        assert rel_l2(v, total[k]) < 1e-5, (k, rel_l2(v, total[k]))
+
+
 def test_eval_points_matches_oracle(oracle32):
     """Renderer::eval_points: raw = (rgb, occ), occ = 100 outside the bound"""
     sc = _scene(5)

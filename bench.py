@@ -29,8 +29,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_16BIT_MFMA_TFLOPS = 2500.0    # same guide, dense BF16 / FP16 MFMA peak
 PEAK_HBM_GBS = 8000.0              # same guide, HBM3E peak
-PMC_FILE = "r02_pmc_hbm.json"      # profiles/: FETCH_SIZE / WRITE_SIZE passes of the default command (tools/profile_round.sh)
+PMC_FILE = "r03_pmc_hbm.json"      # profiles/: FETCH_SIZE / WRITE_SIZE passes of the default command (tools/profile_round.sh)
+PMC_SQ_FILE = "r03_pmc_sq.json"    # profiles/: SQ passes (MFMA busy cycles ...) + GRBM_GUI_ACTIVE of the same command
 
 # algorithmic MACs per sample of each decoder role (DESIGN.md "Kernels")
 MAC = {
@@ -39,9 +41,22 @@ MAC = {
     # trainable: input gradients + embedding-gradient products + weight gradients (block outputs are saved by the forward)
     "bwd_color_train": 9344 + 5952 + 15575,
 }
-# algorithmic HBM bytes per sample: 8 corners x 32 ch x 4 B per level read, 2x that per level scattered (read-modify-write),
-# plus per-sample intermediates (z, outputs, ReLU bits, saved block outputs of the trainable decoder)
-BYTES = {
+# 16-bit matrix products the kernels spend per fp32 multiply-add of the table above: two fp16 pieces = 3 products
+# (forward and backward chains), two bf16 pieces = 4 products (weight-gradient panels); the coarse decoder runs on the fp32 MFMA
+PRODUCTS = {
+    "fwd_coarse": 0.0, "fwd_middle": 3.0, "fwd_fine": 3.0, "fwd_color": 3.0,
+    "bwd_coarse": 0.0, "bwd_middle": 3.0, "bwd_fine": 3.0, "bwd_color": 3.0,
+    "bwd_color_train": (3.0 * (9344 + 5952) + 4.0 * 15575) / (9344 + 5952 + 15575),
+}
+# ALGORITHMIC HBM bytes per sample, exactly SURVEY.md 8(d): 8 corners x 32 ch x 4 B = 1024 B per level looked up, a scatter is a
+# read-modify-write (2048 B per level that receives gradient), ray I/O 5 B per sample; Adam 28 B per MARKED parameter per step
+ALG_BYTES_FWD = {"coarse": 1024 + 5, "middle": 1024 + 5, "fine": 2048 + 5, "color": 3072 + 5}
+ALG_BYTES_BWD = {"coarse": 2048, "middle": 2048, "fine": 2 * 2048, "color": 3 * 2048}
+ADAM_BYTES_PER_PARAM = 28.0
+# what the IMPLEMENTATION moves on top of that, per sample (reported as impl_bytes, never priced as algorithmic): the backward re-reads the
+# features of a trainable decoder's level (1024), per-sample intermediates (z, outputs, g_raw, 32 B of ReLU bits per decoder) and the
+# trainable decoder's saved block outputs (640 B written by the forward, read by the backward)
+IMPL_BYTES = {
     "fwd_coarse": 1024 + 8, "fwd_middle": 1024 + 8, "fwd_fine": 2048 + 8, "fwd_color": 1024 + 20 + 640,
     "bwd_coarse": 2048 + 20, "bwd_middle": 2048 + 52, "bwd_fine": 2048 + 52, "bwd_color": 2048 + 52,
     "bwd_color_train": 3072 + 20 + 640,
@@ -66,13 +81,15 @@ def workloads():
 
 
 def alg_counts(stage, trainable_color):
-    """(MAC, bytes) per sample of the forward and backward launches of a stage"""
+    """per sample, for the forward and the backward launch of a stage: MACs, SURVEY 8(d) bytes, implementation bytes, 16-bit products per MAC"""
     decs = STAGE_DECODERS[stage]
+    bk = lambda d: "bwd_color_train" if (d == "color" and trainable_color) else "bwd_" + d
     fm = sum(MAC["fwd_" + d] for d in decs)
-    fb = sum(BYTES["fwd_" + d] for d in decs)
-    bm = sum(MAC["bwd_color_train" if (d == "color" and trainable_color) else "bwd_" + d] for d in decs)
-    bb = sum(BYTES["bwd_color_train" if (d == "color" and trainable_color) else "bwd_" + d] for d in decs)
-    return fm, fb, bm, bb
+    bm = sum(MAC[bk(d)] for d in decs)
+    fp = sum(MAC["fwd_" + d] * PRODUCTS["fwd_" + d] for d in decs) / max(fm, 1)
+    bp = sum(MAC[bk(d)] * PRODUCTS[bk(d)] for d in decs) / max(bm, 1)
+    return {"fwd": dict(mac=fm, alg_bytes=ALG_BYTES_FWD[stage], impl_bytes=sum(IMPL_BYTES["fwd_" + d] for d in decs), products=fp),
+            "bwd": dict(mac=bm, alg_bytes=ALG_BYTES_BWD[stage], impl_bytes=sum(IMPL_BYTES[bk(d)] for d in decs), products=bp)}
 
 
 def cpu_threads():
@@ -171,11 +188,13 @@ def cpu_baseline_aten(sc, rays_list, stage, lr, w_color, seconds):
 
 
 TUNE = []
-PIPELINE = False
 
 
-def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, frustum=True):
-    """time `steps` mapping iterations of workload `wl` at `N` rays per GPU; returns dict(dt, prof, loss, scene, pool)"""
+def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, frustum=True, matmul_mode=None, pipeline=False,
+                 comm=None, rays_total=None):
+    """time `steps` mapping iterations of workload `wl` at `N` rays per GPU (rays_total: a FIXED batch of that many rays sharded over
+    the ranks instead -- strong scaling); returns dict(dt, prof, loss, scene, pool, ...).  comm: an RCCL communicator for the C-ABI
+    exchange (nsk_allreduce_grads), None = torch.distributed on the packed buffer"""
     import nice_slam_cpp_amd as pkg
     import nice_slam_cpp_amd.dist as nd
     import scenes
@@ -184,12 +203,22 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
     sc = scenes.make_scene(42, scenes.grid_shapes_for(wl["bound"]), bound=wl["bound"])     # grid shapes + init of src/main.cpp:33-78
     # one optimize_map call: a fixed window of 5 frames (4 keyframes + the current frame, mapping_window_size 5), fresh random pixels of
     # those frames every iteration (src/Mapper.cpp:376-414); every rank draws its own pixels of the same frames
-    pool = [scenes.make_rays(1234 + 17 * i + 1000 * rank, N, sc["bound"], n_frames=5, cam_seed=4242, up=wl["up"], **cam) for i in range(8)]
+    if rays_total is None:
+        pool = [scenes.make_rays(1234 + 17 * i + 1000 * rank, N, sc["bound"], n_frames=5, cam_seed=4242, up=wl["up"], **cam) for i in range(8)]
+    else:                                                        # the same batch on every rank, each takes its contiguous shard
+        lo, hi = nd.shard_range(rays_total, rank, world)
+        N = hi - lo
+        pool = []
+        for i in range(8):
+            full = scenes.make_rays(1234 + 17 * i, rays_total, sc["bound"], n_frames=5, cam_seed=4242, up=wl["up"], **cam)
+            pool.append({k: (v[lo:hi] if isinstance(v, np.ndarray) and v.shape[:1] == (rays_total,) else v) for k, v in full.items()})
     ctx = pkg.Context(local)
     for kv in TUNE:                                  # --tune key=value: nsk_set_tuning experiments (include/nsk.h)
         k, v = kv.split("=")
         ctx.set_tuning(k, int(v))
     ctx.set_render_opts()                                        # 32 + 16 samples (src/Renderer.cpp:9-10)
+    if matmul_mode is not None:
+        ctx.set_matmul_mode(matmul_mode)
     ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
     mask_frac = None
     if frustum:                                                  # mapping.frustum_feature_selection: True (nice_slam.yaml:62): the optimiser
@@ -209,21 +238,30 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
         batches.append((cu(r["rays_o"]), cu(r["rays_d"]), gd, cu(r["gt_color"]), gmax))
     loss = torch.zeros(1, device=dev)
     flags = pkg.nsk.GRAD_GRIDS | (pkg.nsk.GRAD_DECODERS if train_color else 0)
+    xev = []                                                     # (start, stop) events around the exchange when it goes through torch.distributed
 
     with torch.cuda.stream(ctx.tstream):
         xn = [0]
+        timing = [False]
 
         def step(i):
             ro, rd, gd, gc, gmax = batches[i % len(batches)]
             ctx.map_step(stage, ro, rd, gd, gc, gmax, w_color, stage == "color", flags=flags, loss=loss)
-            if PIPELINE and not graph:                           # the next batch's sampling + cell sort on the side stream, beside this step
+            if pipeline and not graph:                           # the next batch's sampling + cell sort on the side stream, beside the exchange
                 nro, nrd, ngd, _, ngmax = batches[(i + 1) % len(batches)]
                 ctx.map_prepare(stage, nro, nrd, ngd, ngmax, flags=flags)
             if world > 1:                                        # the one exchange of the path: the marked voxels of the touched levels,
-                buf = ctx.grad_pack()                            # the colour decoder's gradient and the loss (nsk_grad_pack)
-                xn[0] = buf.numel()
-                nd.allreduce_grads(buf)
-                ctx.grad_unpack()
+                if comm is not None:                             # the colour decoder's gradient and the loss
+                    ctx.allreduce_grads_rccl(comm)               # pack -> ncclAllReduce -> unpack on the context's stream, no Python between them
+                else:
+                    buf = ctx.grad_pack()
+                    xn[0] = buf.numel()
+                    if timing[0]:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(); nd.allreduce_grads(buf); e1.record(); xev.append((e0, e1))
+                    else:
+                        nd.allreduce_grads(buf)
+                    ctx.grad_unpack()
             ctx.adam_step(lr)
 
         eager_step = step
@@ -255,44 +293,97 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
             dt = float(t)
         # per-kernel durations: HIP events recorded on the context's stream around every launch (same steps again)
         ctx.profile_begin()
+        timing[0] = True
         for i in range(steps):
             eager_step(warmup + i)
+        timing[0] = False
         prof = ctx.profile_end()
+        if xev:
+            torch.cuda.synchronize()
+            prof["allreduce"] = (len(xev), sum(a.elapsed_time(b) for a, b in xev))
         final_loss = float(loss)
-        if world == 1:                                           # what an exchange would carry (reported also for N = 1)
-            ctx.map_step(stage, *batches[0][:4], batches[0][4], w_color, stage == "color", flags=flags, loss=loss)
-            xn[0] = ctx.grad_pack().numel()
-            ctx.zero_grads()
+        # what an exchange carries (reported also for N = 1)
+        ctx.map_step(stage, *batches[0][:4], batches[0][4], w_color, stage == "color", flags=flags, loss=loss)
+        xn[0] = ctx.grad_pack().numel()
+        ctx.zero_grads()
+    marked = None
+    if mask_frac is not None:
+        marked = sum(mask_frac[k] * sc["grids"][k].size for k in STAGE_DECODERS[stage])
     out = dict(dt=dt, prof=prof, loss=final_loss, sc=sc, pool=pool, lr=lr, w_color=w_color, slab_floats=int(ctx.grad_slab().numel()),
-               exchange_floats=int(xn[0]), mask_frac=mask_frac)
+               exchange_floats=int(xn[0]), mask_frac=mask_frac, marked_params=marked, rays_per_gpu=N)
     ctx.close()
     return out
 
 
-def summarize(res, stage, N, steps, world):
+def sq_profile(kernel_prefix):
+    """MFMA-busy share of the dominant kernel from the committed SQ counter passes of this same command (profiles/, tools/profile_round.sh):
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x the kernel's cycles); the kernel's cycles = GRBM_GUI_ACTIVE / 8 XCDs where that
+    counter was collected, else duration x 2.4 GHz (an upper bound on the cycles, so a lower bound on the share)"""
+    path = os.path.join(ROOT, "profiles", PMC_SQ_FILE)
+    if not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    get = lambda c: next((v for k, v in pmc.items() if k.startswith(kernel_prefix) and k.endswith("|" + c)), None)
+    busy, gui = get("SQ_VALU_MFMA_BUSY_CYCLES"), get("GRBM_GUI_ACTIVE")
+    if busy is None:
+        return None
+    return {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui, "SQ_WAIT_ANY": get("SQ_WAIT_ANY"), "SQ_WAVE_CYCLES": get("SQ_WAVE_CYCLES"),
+            "SQ_LDS_BANK_CONFLICT": get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": get("SQ_LDS_IDX_ACTIVE"), "file": "profiles/" + PMC_SQ_FILE}
+
+
+def summarize(res, stage, N, steps, world, with_counters=False):
     S = 48
     M = N * S
     prof = res["prof"]
     per_kernel = {k: {"launches": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in prof.items()}
-    fm, fb, bm, bb = alg_counts(stage, stage == "color")
+    cnt = alg_counts(stage, stage == "color")
     fwd_name = "decode_fwd_multi" if "decode_fwd_multi" in prof else next(k for k in prof if k.startswith("decode_fwd"))
     bwd_name = "decode_bwd_multi" if "decode_bwd_multi" in prof else next(k for k in prof if k.startswith("decode_bwd"))
-    alg = {fwd_name: (fm, fb), bwd_name: (bm, bb)}
+    alg = {fwd_name: cnt["fwd"], bwd_name: cnt["bwd"]}
     dom = max(alg, key=lambda k: prof[k][1])
     dom_s = prof[dom][1] / prof[dom][0] * 1e-3
-    flops = 2.0 * alg[dom][0] * M
-    roof = {"bound": "mfma", "kernel": dom, "achieved": flops / dom_s / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+    flops = 2.0 * alg[dom]["mac"] * M
+    tf = flops / dom_s / 1e12
+    products = alg[dom]["products"]
+    roof = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
             "avg_launch_us": dom_s * 1e6, "alg_flops_per_launch": flops,
-            "alg_bytes_per_launch": alg[dom][1] * M, "hbm_frac_same_kernel": alg[dom][1] * M / dom_s / 1e9 / PEAK_HBM_GBS}
+            # the same launch against what its own instruction mix allows: every fp32 multiply-add is `products` 16-bit matrix products
+            "products_per_mac": products, "frac_16bit": (tf * products / PEAK_16BIT_MFMA_TFLOPS) if products > 0 else None,
+            "peak_16bit": PEAK_16BIT_MFMA_TFLOPS,
+            # HBM view of the same launch: SURVEY 8(d) bytes only; what the implementation moves on top is impl_bytes_per_launch
+            "alg_bytes_per_launch": float(alg[dom]["alg_bytes"]) * M, "hbm_frac_same_kernel": alg[dom]["alg_bytes"] * M / dom_s / 1e9 / PEAK_HBM_GBS,
+            "impl_bytes_per_launch": float(alg[dom]["impl_bytes"]) * M, "mfma_busy": None}
+    if with_counters:
+        prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "void k_decode_fwd_multi_bf16"}.get(dom)
+        sq = sq_profile(prefix) if prefix else None
+        if sq:
+            cycles = sq["GRBM_GUI_ACTIVE"] / 8.0 if sq["GRBM_GUI_ACTIVE"] else dom_s * 2.4e9
+            roof["mfma_busy"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * 256.0 * cycles)
+            roof["counters"] = sq
     step_s = res["dt"] / steps
     nparam = sum(res["sc"]["grids"][k].size for k in STAGE_DECODERS[stage])
-    step_bytes = float(fb + bb) * M + 28.0 * nparam
-    step_flops = 2.0 * (fm + bm) * M + 1000.0 * M                       # + sampling / compositing
+    marked = res["marked_params"] if res.get("marked_params") is not None else nparam
+    if stage == "color":
+        marked += res["sc"]["decoders"]["color"].size
+    alg_step = float(cnt["fwd"]["alg_bytes"] + cnt["bwd"]["alg_bytes"]) * M + ADAM_BYTES_PER_PARAM * marked
+    impl_step = float(cnt["fwd"]["impl_bytes"] + cnt["bwd"]["impl_bytes"]) * M + ADAM_BYTES_PER_PARAM * marked
+    step_flops = 2.0 * (cnt["fwd"]["mac"] + cnt["bwd"]["mac"]) * M + 1000.0 * M     # + sampling / compositing
     return {"value": world * N / step_s, "ms_per_step": 1e3 * step_s, "roofline": roof,
-            "step_rooflines": {"alg_bytes_per_step": step_bytes, "hbm_frac": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
+            "step_rooflines": {"alg_bytes_per_step": alg_step, "hbm_frac": alg_step / step_s / 1e9 / PEAK_HBM_GBS,
+                               "impl_bytes_per_step": impl_step, "adam_marked_params": marked,
                                "alg_flops_per_step": step_flops, "fp32_frac": step_flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS},
             "kernels": per_kernel, "final_loss": res["loss"]}
+
+
+def extra_line(name, wl, stage, r, s, steps):
+    x = {"workload": wl["name"], "stage": stage, "rays_per_gpu": r["rays_per_gpu"], "steps": steps, "value": s["value"], "unit": "rays/s",
+         "ms_per_step": s["ms_per_step"], "roofline_frac": s["roofline"]["frac"], "roofline_kernel": s["roofline"]["kernel"],
+         "hbm_frac_step": s["step_rooflines"]["hbm_frac"], "kernels_avg_us": {kk: round(v["avg_us"], 2) for kk, v in s["kernels"].items()}}
+    if "allreduce" in s["kernels"]:
+        x["allreduce_us"] = s["kernels"]["allreduce"]["avg_us"]
+        x["exchange_bytes"] = 4 * r["exchange_floats"]
+    return x
 
 
 def main():
@@ -304,17 +395,17 @@ def main():
     ap.add_argument("--rays", type=int, default=0, help="rays per GPU per step (0 = the workload's own count)")
     ap.add_argument("--stage", default="color")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the K2 / fine-stage / K4-shard lines under 'extras'")
+    ap.add_argument("--no-extras", action="store_true", help="skip the lines under 'extras' (K2, K4 shard, fine stage, operand modes; N > 1: K4 at 10000 rays / N, K2, pipeline flipped)")
     ap.add_argument("--no-frustum-mask", action="store_true", help="optimise every voxel (mapping.frustum_feature_selection: False)")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step as a captured hipGraph (single GPU)")
-    ap.add_argument("--pipeline", action="store_true", help="sample the next batch on the side stream (nsk_map_prepare); measured slower on one "
-                    "GPU (K3 0.521 against 0.501 ms, K2 0.164 against 0.151 ms): off by default")
+    ap.add_argument("--pipeline", type=int, default=-1, help="1: sample the next batch on the side stream (nsk_map_prepare) beside the exchange and the optimiser "
+                    "step; 0: off; -1 (default): off on one GPU (measured slower there: K3 0.521 against 0.501 ms), on for N > 1 where the exchange leaves the "
+                    "GPU idle -- the N > 1 run reports the other setting under extras")
+    ap.add_argument("--torch-exchange", action="store_true", help="N > 1: all-reduce the packed buffer through torch.distributed instead of nsk_allreduce_grads")
     ap.add_argument("--tune", action="append", default=[], help="key=value for nsk_set_tuning (experiments), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of each CPU baseline's timed sample")
     args = ap.parse_args()
     TUNE[:] = args.tune
-    global PIPELINE
-    PIPELINE = args.pipeline
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -327,62 +418,104 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
+    comm = None
+    exchange = "none (one GPU)"
     if world > 1:
         import torch.distributed as dist
+        import nice_slam_cpp_amd.dist as nd
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        exchange = "torch.distributed all_reduce of the packed buffer (nsk_grad_pack / nsk_grad_unpack around it)"
+        if not args.torch_exchange and not rehearse:
+            comm = nd.rccl_comm_from_group()                     # ncclUniqueId broadcast over the process group
+            if comm is not None:
+                exchange = "nsk_allreduce_grads (pack -> ncclAllReduce -> unpack on the context's stream; RCCL communicator bootstrapped from the process group)"
+    pipeline = (world > 1) if args.pipeline < 0 else bool(args.pipeline)
 
     W = workloads()
     wl = W[args.workload]
     N = args.rays or wl["rays"]
-    res = run_workload(wl, args.stage, N, args.steps, args.warmup, local, rank, world, dist, graph=args.graph, frustum=not args.no_frustum_mask)
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    head = summarize(res, args.stage, N, args.steps, world)
+    frustum = not args.no_frustum_mask
+    res = run_workload(wl, args.stage, N, args.steps, args.warmup, local, rank, world, dist, graph=args.graph, frustum=frustum, pipeline=pipeline, comm=comm)
+    headline_cfg = args.workload == "K3" and N == W["K3"]["rays"] and args.stage == "color" and frustum
+    head = summarize(res, args.stage, N, args.steps, world, with_counters=headline_cfg) if rank == 0 else None
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same (default) command:
     # FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950
     pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
-    if os.path.exists(pmc_path) and args.workload == "K3" and N == W["K3"]["rays"] and args.stage == "color":
+    if rank == 0 and os.path.exists(pmc_path) and headline_cfg:
         pmc = json.load(open(pmc_path))
         prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "void k_decode_fwd_multi_bf16"}.get(head["roofline"]["kernel"])
         get = lambda c: next((v for k, v in pmc.items() if prefix and k.startswith(prefix) and k.endswith("|" + c)), None)
         if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
             head["roofline"]["traffic"] = (2.0 * get("FETCH_SIZE") + get("WRITE_SIZE")) * 1024.0
-    out = {
-        "metric": "mapping rays/sec (and ms/iter) on CoFusion room1 at 1/2/4/8 MI355X",
-        "value": head["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s; %d rays x 48 samples per GPU, %s-stage mapping iteration (cell sort of the samples + forward + L1 depth/colour loss + "
-                               "backward to the %s grids%s + Adam)" % (wl["name"], N, args.stage, "/".join(STAGE_DECODERS[args.stage]),
-                                                                     " and the colour decoder" if args.stage == "color" else ""),
-                   "id": args.workload, "rays_per_gpu": N, "samples_per_ray": 48, "stage": args.stage,
-                   "grid_shapes": {k: list(v.shape) for k, v in res["sc"]["grids"].items()},
-                   "matmul": "fp32 operands as 16-bit pieces on the matrix cores with fp32 accumulation: forward = two fp16 pieces (22 significant bits, "
-                             "3 MFMAs per K=32 block); backward chains (frozen and trainable decoders) = two fp16 pieces of a per-sample power-of-two "
-                             "multiple of the gradient; the trainable decoder's weight-gradient panels = two bf16 pieces (16 bits, fp32 sums); fp32 MFMA "
-                             "for the grid-gradient scatter",
-                   "frustum_feature_selection": res["mask_frac"] is not None, "marked_voxel_fraction": res["mask_frac"],
-                   "parallelism": "rays sharded x%d, 1 all-reduce/step of %d floats (%.2f MB: marked voxels of the trained levels + colour decoder + loss; "
-                                  "the dense gradient slab is %d floats)" % (world, res["exchange_floats"], 4e-6 * res["exchange_floats"], res["slab_floats"])},
-        "roofline": head["roofline"], "step_rooflines": head["step_rooflines"], "kernels": head["kernels"], "final_loss": head["final_loss"],
-    }
-    if world == 1 and not args.no_extras:
+            head["roofline"]["traffic_source"] = "profiles/" + PMC_FILE
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "mapping rays/sec (and ms/iter) on CoFusion room1 at 1/2/4/8 MI355X",
+            "value": head["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "dtype_detail": "fp32 storage and accumulation; matrix operands as two fp16 pieces (22 significant bits: forward, backward chains) or two "
+                                            "bf16 pieces (16 bits: weight-gradient panels); fp32 MFMA for the grid-gradient scatter",
+            "data": "synthetic",
+            "config": {"workload": "%s; %d rays x 48 samples per GPU, %s-stage mapping iteration (cell sort of the samples + forward + L1 depth/colour loss + "
+                                   "backward to the %s grids%s + Adam)" % (wl["name"], N, args.stage, "/".join(STAGE_DECODERS[args.stage]),
+                                                                         " and the colour decoder" if args.stage == "color" else ""),
+                       "id": args.workload, "rays_per_gpu": N, "samples_per_ray": 48, "stage": args.stage,
+                       "grid_shapes": {k: list(v.shape) for k, v in res["sc"]["grids"].items()},
+                       "matmul": "fp32 operands as 16-bit pieces on the matrix cores with fp32 accumulation: forward = two fp16 pieces (22 significant bits, "
+                                 "3 MFMAs per K=32 block); backward chains (frozen and trainable decoders) = two fp16 pieces of a per-sample power-of-two "
+                                 "multiple of the gradient; the trainable decoder's weight-gradient panels = two bf16 pieces (16 bits, fp32 sums); fp32 MFMA "
+                                 "for the grid-gradient scatter",
+                       "frustum_feature_selection": res["mask_frac"] is not None, "marked_voxel_fraction": res["mask_frac"],
+                       "exchange": exchange, "pipeline": pipeline,
+                       "parallelism": "rays sharded x%d, 1 all-reduce/step of %d floats (%.2f MB: marked voxels of the trained levels + colour decoder + loss; "
+                                      "the dense gradient slab is %d floats)" % (world, res["exchange_floats"], 4e-6 * res["exchange_floats"], res["slab_floats"])},
+            "roofline": head["roofline"], "step_rooflines": head["step_rooflines"], "kernels": head["kernels"], "final_loss": head["final_loss"],
+        }
+        if "allreduce" in head["kernels"]:
+            out["allreduce_us"] = head["kernels"]["allreduce"]["avg_us"]
+            out["exchange_bytes"] = 4 * res["exchange_floats"]
+    if not args.no_extras:
+        # every rank runs the extras (at N > 1 they exchange); rank 0 reports.  N = 1: the other BASELINE configs and the operand modes;
+        # N > 1: configs[3] as BASELINE states it (a FIXED 10000-ray batch sharded over the ranks: strong scaling), configs[1], and the
+        # headline with the pipeline setting flipped -- the driver's one run per N is the only node time there is
+        plan = []
+        if world == 1:
+            plan += [("K3_fine_stage", "K3", "fine", dict(N=W["K3"]["rays"]), 100), ("K2_color", "K2", "color", dict(N=W["K2"]["rays"]), 300),
+                     ("K4_shard_color", "K4", "color", dict(N=W["K4"]["rays"]), 300),
+                     ("K3_color_mode0", "K3", "color", dict(N=W["K3"]["rays"], matmul_mode=0), 100),
+                     ("K3_color_mode1", "K3", "color", dict(N=W["K3"]["rays"], matmul_mode=1), 100),
+                     ("K3_color_no_mask", "K3", "color", dict(N=W["K3"]["rays"], frustum=False), 100)]
+        else:
+            plan += [("K4_strong_10000_rays", "K4", "color", dict(N=0, rays_total=10000), 300), ("K2_color", "K2", "color", dict(N=W["K2"]["rays"]), 300),
+                     ("K3_pipeline_%s" % ("off" if pipeline else "on"), "K3", "color", dict(N=W["K3"]["rays"], pipeline=not pipeline), args.steps)]
         extras = {}
-        for name, wname, stage, n, k in (("K3_fine_stage", "K3", "fine", W["K3"]["rays"], 100), ("K2_color", "K2", "color", W["K2"]["rays"], 300),
-                                         ("K4_shard_color", "K4", "color", W["K4"]["rays"], 300)):
-            if wname == args.workload and stage == args.stage and n == N:
+        for name, wname, stage, kw, k in plan:
+            n = kw.pop("N")
+            if world == 1 and wname == args.workload and stage == args.stage and n == N and not kw:
                 continue
-            r = run_workload(W[wname], stage, n, k, 20, local, rank, world, None, frustum=not args.no_frustum_mask)
-            s = summarize(r, stage, n, k, 1)
-            extras[name] = {"workload": W[wname]["name"], "stage": stage, "rays": n, "steps": k, "value": s["value"], "unit": "rays/s",
-                            "ms_per_step": s["ms_per_step"], "roofline_frac": s["roofline"]["frac"], "roofline_kernel": s["roofline"]["kernel"],
-                            "kernels_avg_us": {kk: round(v["avg_us"], 2) for kk, v in s["kernels"].items()}}
-        out["extras"] = extras
+            kw.setdefault("frustum", frustum)
+            kw.setdefault("pipeline", pipeline if world > 1 else False)
+            r = run_workload(W[wname], stage, n, k, 20, local, rank, world, dist, comm=comm, **kw)
+            if rank != 0:
+                continue
+            sm = summarize(r, stage, r["rays_per_gpu"], k, world)
+            extras[name] = extra_line(name, W[wname], stage, r, sm, k)
+            if kw.get("rays_total"):
+                extras[name]["scaling"] = "strong"
+                extras[name]["rays_total"] = kw["rays_total"]
+                extras[name]["value"] = kw["rays_total"] / (1e-3 * sm["ms_per_step"])
+            if "matmul_mode" in kw:
+                extras[name]["forward_operands"] = {0: "fp32 MFMA (v_mfma_f32_16x16x4_f32)", 1: "three bf16 pieces (24 bits)"}[kw["matmul_mode"]]
+        if rank == 0:
+            out["extras"] = extras
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_aten(res["sc"], res["pool"], args.stage, res["lr"], res["w_color"], args.cpu_seconds)
         out["cpu_baseline_c_port"] = cpu_baseline_c(res["sc"], res["pool"], args.stage, res["lr"], res["w_color"], args.cpu_seconds)

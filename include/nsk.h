@@ -279,7 +279,10 @@ int nsk_adam_reset(nsk_ctx* ctx);
  * device buffers, sizes, learning rates and a device-computed or fixed gt_depth_max) are recorded instead of run, and
  * nsk_graph_launch replays them with one launch on the context's stream; Adam's step counts advance per replay (the recorded
  * Adam node is patched with the new bias-correction constants).  Run the step once eagerly first (workspaces are sized then);
- * at most one nsk_adam_step per graph; calls that synchronise (uploads, downloads, nsk_grad_slab) are not capturable. */
+ * at most one nsk_adam_step per graph; calls that synchronise (uploads, downloads, nsk_grad_slab) are not capturable.
+ * A recorded step holds buffer addresses and the optimiser masks' voxel lists as kernel arguments: after a reallocation (larger
+ * batch, new grid shape) or ANY nsk_set_mask / nsk_frustum_mask call (new mask contents included) every graph is stale --
+ * nsk_graph_launch then fails with a message instead of replaying; run the step eagerly once and capture again. */
 int nsk_graph_begin(nsk_ctx* ctx);
 int nsk_graph_end(nsk_ctx* ctx, int* graph_id);
 int nsk_graph_launch(nsk_ctx* ctx, int graph_id);

@@ -785,6 +785,7 @@ struct ProfScope {      // records start/stop events around the launches issued 
 static void invalidate_graphs(nsk_ctx* c)
 {
     for (auto& R : c->graphs) {
+        if (R.stale) continue;
         if (R.exec) { hipGraphExecDestroy(R.exec); R.exec = nullptr; }
         if (R.graph) { hipGraphDestroy(R.graph); R.graph = nullptr; }
         R.stale = true;
@@ -1046,14 +1047,18 @@ extern "C" int nsk_set_mask(nsk_ctx* c, int level, const uint8_t* h_mask)
     if (!c || !which_ok(level)) return fail("nsk_set_mask: bad argument");
     GridState& G = c->grid[level];
     if (!G.n) return fail("nsk_set_mask: grid level %d not uploaded", level);
+    if (c->capturing) return fail("nsk_set_mask: not while a graph is being captured");
     HIPCHK(hipStreamSynchronize(c->stream));
     size_t nvox = G.n / 32;
     G.midx_dirty = true;
+    // A captured step holds the level's voxel list as kernel arguments (its pointer, its length and the block ranges derived from it:
+    // k_adam_multi, k_xchg_multi): new mask CONTENTS make every recorded graph wrong, not only a new allocation.
+    invalidate_graphs(c);
     // Unmarked voxels are never visited by the optimiser, so whatever the scatter added to their gradient stays there: a voxel that
     // becomes marked now must not inherit it.  The level's gradient is cleared whenever its mask changes.
     if (c->slab) HIPCHK(hipMemsetAsync(c->slab + G.g_off, 0, G.n * 4, c->stream));
-    if (!h_mask) { if (G.mask) { invalidate_graphs(c); hipFree(G.mask); G.mask = nullptr; } return 0; }
-    if (!G.mask) { invalidate_graphs(c); HIPCHK(hipMalloc(&G.mask, nvox)); }
+    if (!h_mask) { if (G.mask) { hipFree(G.mask); G.mask = nullptr; } return 0; }
+    if (!G.mask) HIPCHK(hipMalloc(&G.mask, nvox));
     HIPCHK(hipMemcpy(G.mask, h_mask, nvox, hipMemcpyHostToDevice));
     return 0;
 }
@@ -1795,7 +1800,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         }
         MA.which[n] = w; MA.train[n] = train ? 1 : 0;
         // relative cost of one tile of a frozen role against one 8-tile iteration of the trainable role (= 1000)
-        const int frozen_cost = c->tune_frozen_cost > 0 ? c->tune_frozen_cost : 165;
+        const int frozen_cost = c->tune_frozen_cost > 0 ? c->tune_frozen_cost : 205;
         cost[n] = train ? 1000 : frozen_cost;
         lds = std::max(lds, bwd_lds_bytes(w, train));
         if (train) train_role = (train_role == -1 && w != 2) ? n : -2;     // -2: more than one trainable decoder, or the fine one (its
@@ -2026,6 +2031,13 @@ extern "C" int nsk_dbg_read_ph(nsk_ctx* c, unsigned long long* out)      // [8][
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_dbg_ph), sizeof(unsigned long long) * 8 * 8 * 96));
     return 0;
 }
+extern "C" int nsk_dbg_read_oob(nsk_ctx* c, unsigned* out, int clear)      // [8]: out-of-range index counts by site (NSK_IDX, nsk_device.h)
+{
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_dbg_oob), sizeof(unsigned) * 8));
+    if (clear) { unsigned z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nsk_dbg_oob), z, sizeof(z))); }
+    return 0;
+}
 extern "C" int nsk_dbg_read_ts(nsk_ctx* c, unsigned long long* out)      // [2][1024][4]
 {
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2043,8 +2055,12 @@ extern "C" int nsk_frustum_mask(nsk_ctx* c, int level, const float* d_depth, int
     HIPCHK(hipSetDevice(c->device));
     const size_t nvox = G.n / 32;
     G.midx_dirty = true;
+    if (c->capturing) return fail("nsk_frustum_mask: not while a graph is being captured");
+    bool live = false;
+    for (auto& R : c->graphs) live = live || !R.stale;
+    if (live) { HIPCHK(hipStreamSynchronize(c->stream)); invalidate_graphs(c); }      // new mask contents: see nsk_set_mask
     if (c->slab) HIPCHK(hipMemsetAsync(c->slab + G.g_off, 0, G.n * 4, c->stream));       // see nsk_set_mask
-    if (!G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); invalidate_graphs(c); HIPCHK(hipMalloc(&G.mask, nvox)); }
+    if (!G.mask) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMalloc(&G.mask, nvox)); }
     if (level == NSK_COARSE) {                                   // src/Mapper.cpp:54-59
         HIPCHK(hipMemsetAsync(G.mask, 1, nvox, c->stream));
     } else {
@@ -2538,7 +2554,8 @@ extern "C" int nsk_allreduce_grads(nsk_ctx* c, void* comm)
     float* buf = nullptr; size_t n = 0;
     CHK(nsk_grad_pack(c, &buf, &n));
     const int ncclFloat32 = 7, ncclSum = 0;
-    int r = fn(buf, buf, n, ncclFloat32, ncclSum, comm, c->stream);
+    int r;
+    { ProfScope ps(c, "allreduce"); r = fn(buf, buf, n, ncclFloat32, ncclSum, comm, c->stream); }      // HIP events on the context's stream: the collective alone
     if (r != 0) return fail("ncclAllReduce failed with %d", r);
     return nsk_grad_unpack(c);
 }

@@ -24,6 +24,12 @@ struct GridD {              // one feature grid level, voxel-major [Z][Y][X][32]
 #define NSK_INF __builtin_huge_valf()
 #ifdef NSK_EXPERIMENT
 __device__ int nsk_dbg_flags;
+// range audit of every index that addresses a per-sample array in the decoder bodies (experiment builds; tools/exp_idx.py): counts of
+// indices outside [0, n) by site -- 0 perm entry, 1 sample index, 2 slot (ReLU bits), 3 tile (saved block outputs), 4 ray
+__device__ unsigned nsk_dbg_oob[8];
+#define NSK_IDX(site, i, n) do { if ((long long)(i) < 0 || (long long)(i) >= (long long)(n)) atomicAdd(&nsk_dbg_oob[site], 1u); } while (0)
+#else
+#define NSK_IDX(site, i, n)
 #endif
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -53,7 +59,6 @@ __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, 
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
-
 // at::linspace CPU kernel (reference src/Renderer.cpp:86,101)
 __device__ __forceinline__ float linspace01(int i, int steps)
 {
@@ -767,19 +772,28 @@ __device__ __forceinline__ int ray_of(const DecArgs& A, int mm) { return A.S_mag
 __device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px, float& py, float& pz, float& zz, int& n)
 {
     if (A.pts) { px = A.pts[3 * mm]; py = A.pts[3 * mm + 1]; pz = A.pts[3 * mm + 2]; zz = 0.f; n = 0; return; }
+    NSK_IDX(1, mm, A.M);
     n = ray_of(A, mm);           // = mm / A.S (the generic division is ~25 vector instructions)
+    NSK_IDX(4, n, (A.M + A.S - 1) / A.S);
     zz = A.z[mm];
     px = add_rn(A.rays_o[3 * n], mul_rn(A.rays_d[3 * n], zz));           // reference src/Renderer.cpp:121
     py = add_rn(A.rays_o[3 * n + 1], mul_rn(A.rays_d[3 * n + 1], zz));
     pz = add_rn(A.rays_o[3 * n + 2], mul_rn(A.rays_d[3 * n + 2], zz));
 }
 
-// the same in two steps, for software pipelining: the loads (no arithmetic on their results) and the point
+// the same in two steps, for software pipelining: the loads (no arithmetic on their results) and the point.
+// (Round 3 tried one 16-byte record (px, py, pz, z) per sample written by k_sample, re-ordered by k_sort_place, instead of these seven loads:
+// the forward got 7 us SLOWER at K3 on the same box, sampling + sort 6 us slower -- the ray arrays are cache-resident, the records stream --
+// and parity moved: forming p in another kernel changes whether the compiler fuses o + d z, p moves by an ulp, p.B by ~1e-5 rad, and
+// ReLUs within that of zero flip: K3 colour-grid gradient 3.5e-4 -> 1.15e-3 from the oracle, the very figure round 2's 32-bit addressing
+// experiment met; the index audit of tools/exp_idx.py is clean, so that discrepancy was this rounding effect, not an out-of-range read.)
 struct SampleRaw { float z, o[3], d[3]; };
 __device__ __forceinline__ void sample_load(const DecArgs& A, int mm, SampleRaw& R)
 {
     if (A.pts) { R.o[0] = A.pts[3 * mm]; R.o[1] = A.pts[3 * mm + 1]; R.o[2] = A.pts[3 * mm + 2]; R.z = 0.f; R.d[0] = R.d[1] = R.d[2] = 0.f; return; }
+    NSK_IDX(1, mm, A.M);
     const int n = ray_of(A, mm);     // = mm / A.S
+    NSK_IDX(4, n, (A.M + A.S - 1) / A.S);
     R.z = A.z[mm];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { R.o[k] = A.rays_o[3 * n + k]; R.d[k] = A.rays_d[3 * n + k]; }
@@ -798,6 +812,10 @@ __device__ __forceinline__ void sample_finish(const DecArgs& A, const SampleRaw&
 __device__ __forceinline__ int slot_sample(const DecArgs& A, int slot)
 {
     const int s = min(slot, A.M - 1);
+    NSK_IDX(2, s, A.M);
+#ifdef NSK_EXPERIMENT
+    if (A.perm) { const int v = A.perm[s]; NSK_IDX(0, v, A.M); return v; }
+#endif
     return A.perm ? A.perm[s] : s;
 }
 
@@ -1286,6 +1304,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     auto slot_of = [&](int task_) { return min(min(task_, ntasks - 1) * 16 + j, A.M - 1); };
     auto stage = [&](int task_, int mm_, Staged& S_) {
         const int sl_ = slot_of(task_);
+        NSK_IDX(2, sl_, A.M);
         sample_load(A, mm_, S_.r);
         S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm_ * 4);
         S_.mask = A.masks[(size_t)sl_ * 4 + g];

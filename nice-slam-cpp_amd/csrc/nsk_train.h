@@ -10,6 +10,7 @@
 #pragma once
 #include "nsk_device.h"
 #include <type_traits>
+#include <utility>
 
 // The panel holds every element as its two leading bf16 pieces, h = bf16(x) and m = bf16(x - h), in two PLANES of 16-bit values:
 // plane H at the panel base, plane M PN_MOFF(CQ) bytes behind it, rows of 128 samples (256 B) + 16 B pad.  The pad makes a row step
@@ -122,6 +123,56 @@ __device__ __forceinline__ void pn_put(char* __restrict__ pn, int moff, int row0
         *reinterpret_cast<unsigned short*>(ph + (2 * p + 1) * PN_RB) = (unsigned short)(h01 >> 16);
         *reinterpret_cast<unsigned short*>(ph + moff + (2 * p) * PN_RB) = (unsigned short)m01;
         *reinterpret_cast<unsigned short*>(ph + moff + (2 * p + 1) * PN_RB) = (unsigned short)(m01 >> 16);
+    }
+}
+
+// Half-word masks of a layer's eight ReLU bits: dword d covers elements 2d (low half) and 2d + 1 (high half) of the lane's block -- the
+// packing both the fp16 chain pieces (H2) and the bf16 panel pieces (pn_put) use.  v_bfe_i32 spreads a bit over a dword, v_bfi_b32 joins
+// two of them: three instructions per dword.
+struct Mask4 { unsigned d[4]; };
+__device__ __forceinline__ Mask4 relu_mask_dwords(unsigned long long mask, int l)
+{
+    const unsigned w = l < 4 ? (unsigned)mask : (unsigned)(mask >> 32);
+    const int sh = l < 4 ? 8 * l : 0;
+    Mask4 M;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)w, sh + 2 * d, 1), hi = (unsigned)__builtin_amdgcn_sbfe((int)w, sh + 2 * d + 1, 1);
+        M.d[d] = (lo & 0xffffu) | (hi & 0xffff0000u);
+    }
+    return M;
+}
+__device__ __forceinline__ H2 mask_block_h4(const H2& x, const Mask4& M)
+{
+    u4v h = __builtin_bit_cast(u4v, x.h), l = __builtin_bit_cast(u4v, x.l);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { h[d] &= M.d[d]; l[d] &= M.d[d]; }
+    H2 r;
+    r.h = __builtin_bit_cast(h8, h); r.l = __builtin_bit_cast(h8, l);
+    return r;
+}
+// pn_put of a gradient quad x (rows row1..) TOGETHER with its ReLU-masked copy (rows row2..): g_a = ReLU'(.) g_h, and the pieces of a zero
+// are zeros, so the masked quad's pieces are the quad's pieces ANDed with the half-word masks -- one scale and one split for both.
+__device__ __forceinline__ void pn_put_masked(char* __restrict__ pn, int moff, int row1, int row2, int wave, int lane, f4 x, float us, unsigned m01, unsigned m23)
+{
+    x *= us;
+    const int j = lane & 15, g = lane >> 4;
+    char* p1 = pn + (row1 + 4 * g) * PN_RB + (16 * wave + j) * 2;
+    char* p2 = p1 + (row2 - row1) * PN_RB;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        unsigned h01, m01_;
+        split2_pair(x[2 * p], x[2 * p + 1], h01, m01_);
+        const unsigned k = p ? m23 : m01;
+        const unsigned ha = h01 & k, ma = m01_ & k;
+        *reinterpret_cast<unsigned short*>(p1 + (2 * p) * PN_RB) = (unsigned short)h01;
+        *reinterpret_cast<unsigned short*>(p1 + (2 * p + 1) * PN_RB) = (unsigned short)(h01 >> 16);
+        *reinterpret_cast<unsigned short*>(p1 + moff + (2 * p) * PN_RB) = (unsigned short)m01_;
+        *reinterpret_cast<unsigned short*>(p1 + moff + (2 * p + 1) * PN_RB) = (unsigned short)(m01_ >> 16);
+        *reinterpret_cast<unsigned short*>(p2 + (2 * p) * PN_RB) = (unsigned short)ha;
+        *reinterpret_cast<unsigned short*>(p2 + (2 * p + 1) * PN_RB) = (unsigned short)(ha >> 16);
+        *reinterpret_cast<unsigned short*>(p2 + moff + (2 * p) * PN_RB) = (unsigned short)ma;
+        *reinterpret_cast<unsigned short*>(p2 + moff + (2 * p + 1) * PN_RB) = (unsigned short)(ma >> 16);
     }
 }
 
@@ -608,17 +659,193 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
 #define PM_LDS_BYTES (PM_IMG_F * 4 + PM_ROWS * PN_RB * 2)
 
 // acc[0..5] += W?e^T x with the fragments read from global memory, one 32-row slice (4 fragment loads) at a time
-__device__ __forceinline__ void gemm_e2_global(const h8* __restrict__ gimg, int lane, const H2& x3, const H2& x0, f4 (&acc)[6])
+// the same from an LDS copy of fragment groups W0ET..W3ET+5 (group index relative to W0ET)
+__device__ __forceinline__ void gemm_e2_lds(const h8* __restrict__ eimg, int lane, const H2& x3, const H2& x0, f4 (&acc)[6])
 {
+    constexpr int G3 = MlpBwdImgH::W3ET - MlpBwdImgH::W0ET;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const FragH a30 = load_frag_h(gimg, MlpBwdImgH::W3ET + 2 * a, lane), a31 = load_frag_h(gimg, MlpBwdImgH::W3ET + 2 * a + 1, lane);
-        const FragH a00 = load_frag_h(gimg, MlpBwdImgH::W0ET + 2 * a, lane), a01 = load_frag_h(gimg, MlpBwdImgH::W0ET + 2 * a + 1, lane);
+        const FragH a30 = load_frag_h(eimg, G3 + 2 * a, lane), a31 = load_frag_h(eimg, G3 + 2 * a + 1, lane);
+        const FragH a00 = load_frag_h(eimg, 2 * a, lane), a01 = load_frag_h(eimg, 2 * a + 1, lane);
         f4 tH[2] = {acc[2 * a], acc[2 * a + 1]}, tL[2] = {(f4)(0.f), (f4)(0.f)};
         mac_block_h(a30, a31, x3, tH, tL);
         mac_block_h(a00, a01, x0, tH, tL);
         acc[2 * a] = tH[0] + tL[0] * (1.f / NSK_H16_SCALE); acc[2 * a + 1] = tH[1] + tL[1] * (1.f / NSK_H16_SCALE);
     }
+}
+// (the loads of slice a + 1 are issued before the products of slice a: written slice by slice, every slice opened with a wait for an L2
+// round trip -- three of them, ~1 000 cycles each, per tile)
+struct FragE { FragH a30, a31, a00, a01; };
+__device__ __forceinline__ FragE load_frag_e(const h8* __restrict__ gimg, int a, int lane)
+{
+    FragE F;
+    F.a30 = load_frag_h(gimg, MlpBwdImgH::W3ET + 2 * a, lane); F.a31 = load_frag_h(gimg, MlpBwdImgH::W3ET + 2 * a + 1, lane);
+    F.a00 = load_frag_h(gimg, MlpBwdImgH::W0ET + 2 * a, lane); F.a01 = load_frag_h(gimg, MlpBwdImgH::W0ET + 2 * a + 1, lane);
+    return F;
+}
+__device__ __forceinline__ void gemm_e2_global(const h8* __restrict__ gimg, int lane, const H2& x3, const H2& x0, f4 (&acc)[6])
+{
+    FragE F[3];
+    F[0] = load_frag_e(gimg, 0, lane);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#ifdef NSK_V_NOGE
+        if (a > 0) F[a] = load_frag_e(gimg, a, lane);
+#else
+        if (a + 1 < 3) F[a + 1] = load_frag_e(gimg, a + 1, lane);
+#endif
+        f4 tH[2] = {acc[2 * a], acc[2 * a + 1]}, tL[2] = {(f4)(0.f), (f4)(0.f)};
+        mac_block_h(F[a].a30, F[a].a31, x3, tH, tL);
+        mac_block_h(F[a].a00, F[a].a01, x0, tH, tL);
+        acc[2 * a] = tH[0] + tL[0] * (1.f / NSK_H16_SCALE); acc[2 * a + 1] = tH[1] + tL[1] * (1.f / NSK_H16_SCALE);
+    }
+}
+
+// ---- weight-gradient tiles of the merged-phase body as JOBS (round 3) ------------------------------------------------------------------------
+// A job = one wave, one 16-row block of G (the A operand) and up to four 16x16 output tiles that share it: X blocks (the B operands) or the
+// row sums (bias gradients).  The A fragments are read once per job and K-step instead of once per tile (a layer's twelve tiles read 160
+// fragments, its four to eight jobs 96 to 128: the tile phases are bound by LDS reads, not by the matrix pipe -- 1 000 cycles per tile and wave
+// against 256 of MFMA, tools/exp_ph3.py), and the jobs of every phase are dealt so that the two waves of each SIMD (w, w + 4) carry the same
+// number of tiles and no wave owns more than twelve tiles in all: 48 accumulator registers instead of 60.
+struct TJob { int wave, grow, nt; int xrow[4]; int ph[4]; int rt; int ch[4]; };      // ch < 0: row sums (xrow unused)
+template <int WHICH>
+struct JobPlan {
+    typedef TrainPlan<WHICH> PL;
+    static constexpr int NJ = 32;
+    static constexpr int PH_OUT = 0, PH_DB = 6;          // panel phases: 0 OUT, 1 + (4 - l) layer l, 6 DB
+    TJob j[NJ];
+    int slot0[NJ];
+    int first[8];                                        // first job of each panel phase (first[7] = NJ)
+    int nslots;
+    constexpr JobPlan() : j{}, slot0{}, first{}, nslots(0)
+    {
+        int n = 0;
+        auto add = [&](int wave, int grow, int rt, int nt, int x0, int p0, int c0, int x1, int p1, int c1, int x2 = 0, int p2 = 0, int c2 = 0, int x3 = 0, int p3 = 0, int c3 = 0) {
+            j[n] = TJob{wave, grow, nt, {x0, x1, x2, x3}, {p0, p1, p2, p3}, rt, {c0, c1, c2, c3}};
+            ++n;
+        };
+        const int RS = -1;
+        // phase OUT: G1 = g_out, X = h4
+        first[0] = n;
+        add(0, PM_G1, 0, 3, PM_XH, PL::P_OUT, 0, PM_XH + 16, PL::P_OUT, 1, 0, PL::P_OUT, RS);
+        for (int l = 4; l >= 0; --l) {
+            first[1 + (4 - l)] = n;
+            const int FC = PL::P_FC0 + l, W = PL::P_W0 + l;
+            if (l == 4 || l == 2 || l == 1) {            // four jobs of three tiles, one per SIMD; the waves alternate to even out the totals
+                const int w0 = l == 4 ? 0 : 4;
+                add(w0 + 0, PM_G1, 0, 3, PM_XC, FC, 0, PM_XC + 16, FC, 1, 0, FC, RS);
+                add(w0 + 1, PM_G1 + 16, 1, 3, PM_XC, FC, 0, PM_XC + 16, FC, 1, 0, FC, RS);
+                add(w0 + 2, PM_G2, 0, 3, PM_XH, W, 0, PM_XH + 16, W, 1, 0, W, RS);
+                add(w0 + 3, PM_G2 + 16, 1, 3, PM_XH, W, 0, PM_XH + 16, W, 1, 0, W, RS);
+            } else if (l == 3) {                         // 24 tiles: six per SIMD
+                add(0, PM_G2, 0, 3, PM_E, W, 0, PM_E + 16, W, 1, 0, W, RS);
+                add(4, PM_G1, 0, 3, PM_XC, FC, 0, PM_XC + 16, FC, 1, 0, FC, RS);
+                add(1, PM_G2 + 16, 1, 3, PM_E, W, 0, PM_E + 16, W, 1, 0, W, RS);
+                add(5, PM_G1 + 16, 1, 3, PM_XC, FC, 0, PM_XC + 16, FC, 1, 0, FC, RS);
+                add(2, PM_G2, 0, 4, PM_E + 32, W, 2, PM_E + 48, W, 3, PM_XH, PL::P_W3H, 0, PM_XH + 16, PL::P_W3H, 1);
+                add(6, PM_G2, 0, 2, PM_E + 64, W, 4, PM_E + 80, W, 5);
+                add(3, PM_G2 + 16, 1, 4, PM_E + 32, W, 2, PM_E + 48, W, 3, PM_XH, PL::P_W3H, 0, PM_XH + 16, PL::P_W3H, 1);
+                add(7, PM_G2 + 16, 1, 2, PM_E + 64, W, 4, PM_E + 80, W, 5);
+            } else {                                     // l == 0: 20 tiles, five per SIMD
+                add(0, PM_G2, 0, 3, PM_E, W, 0, PM_E + 16, W, 1, 0, W, RS);
+                add(4, PM_G2, 0, 2, PM_E + 32, W, 2, PM_E + 48, W, 3);
+                add(1, PM_G2 + 16, 1, 3, PM_E, W, 0, PM_E + 16, W, 1, 0, W, RS);
+                add(5, PM_G2 + 16, 1, 2, PM_E + 32, W, 2, PM_E + 48, W, 3);
+                add(2, PM_G1, 0, 3, PM_XC, FC, 0, PM_XC + 16, FC, 1, 0, FC, RS);
+                add(6, PM_G2, 0, 2, PM_E + 64, W, 4, PM_E + 80, W, 5);
+                add(3, PM_G1 + 16, 1, 3, PM_XC, FC, 0, PM_XC + 16, FC, 1, 0, FC, RS);
+                add(7, PM_G2 + 16, 1, 2, PM_E + 64, W, 4, PM_E + 80, W, 5);
+            }
+        }
+        first[6] = n;                                    // phase DB: G1 = p (3 rows), X = g_s
+        add(6, PM_G1, 0, 2, PM_E, PL::P_DB, 0, PM_E + 16, PL::P_DB, 1);
+        add(7, PM_G1, 0, 2, PM_E + 32, PL::P_DB, 2, PM_E + 48, PL::P_DB, 3);
+        add(1, PM_G1, 0, 2, PM_E + 64, PL::P_DB, 4, PM_E + 80, PL::P_DB, 5);
+        first[7] = n;
+        int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < n; ++q) { slot0[q] = used[j[q].wave]; used[j[q].wave] += j[q].nt; }
+        for (int w = 0; w < 8; ++w) nslots = used[w] > nslots ? used[w] : nslots;
+    }
+};
+
+template <int WHICH, int JJ>
+__device__ __forceinline__ void pn_job(const char* __restrict__ pn, int moff, int wave, int lane, f4* acc)
+{
+    constexpr JobPlan<WHICH> JP{};
+    constexpr TJob J = JP.j[JJ];
+    constexpr int s0 = JP.slot0[JJ];
+    if (wave != J.wave) return;
+    const int r = lane & 15, sq = lane >> 4;
+    const char* ga = pn + (J.grow + r) * PN_RB + 16 * sq;
+    f4 d0[J.nt], d1[J.nt];
+#pragma unroll
+    for (int k = 0; k < J.nt; ++k) { d0[k] = acc[s0 + k]; d1[k] = (f4)(0.f); }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {                       // 32 samples per step
+        const bf8 ah = *reinterpret_cast<const bf8*>(ga + 64 * b);
+        const bf8 am = *reinterpret_cast<const bf8*>(ga + moff + 64 * b);
+#pragma unroll
+        for (int k = 0; k < J.nt; ++k) {
+            if (J.ch[k] < 0) {                          // row sums: every operand slot of B is 1.0
+                const bf8 one = __builtin_bit_cast(bf8, (u4v)(0x3f803f80u));
+                d0[k] = mfma_b(ah, one, d0[k]);
+                d1[k] = mfma_b(am, one, d1[k]);
+            } else {
+                const char* xb = pn + (J.xrow[k] + r) * PN_RB + 16 * sq;
+                const bf8 xh = *reinterpret_cast<const bf8*>(xb + 64 * b);
+                const bf8 xm = *reinterpret_cast<const bf8*>(xb + moff + 64 * b);
+                d0[k] = mfma_b(ah, xh, d0[k]);
+                d1[k] = mfma_b(am, xm, d1[k]);
+                d0[k] = mfma_b(ah, xm, d0[k]);
+                d1[k] = mfma_b(am, xh, d1[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < J.nt; ++k) acc[s0 + k] = d0[k] + d1[k];
+}
+template <int WHICH, int J0, int... Is>
+__device__ __forceinline__ void pn_jobs_seq(const char* __restrict__ pn, int moff, int wave, int lane, f4* acc, std::integer_sequence<int, Is...>)
+{
+    (pn_job<WHICH, J0 + Is>(pn, moff, wave, lane, acc), ...);
+}
+// all jobs of panel phase PH (0 OUT, 1..5 layers 4..0, 6 DB)
+template <int WHICH, int PH>
+__device__ __forceinline__ void pn_phase_jobs(const char* __restrict__ pn, int moff, int wave, int lane, f4* acc)
+{
+    constexpr JobPlan<WHICH> JP{};
+    pn_jobs_seq<WHICH, JP.first[PH]>(pn, moff, wave, lane, acc, std::make_integer_sequence<int, JP.first[PH + 1] - JP.first[PH]>{});
+}
+// store the tiles of job JJ (if this wave owns it) into the workgroup's slab, canonical parameter layout
+template <int WHICH, int JJ>
+__device__ __forceinline__ void pn_job_flush(float* __restrict__ g_dec, int wave, int lane, const f4* acc)
+{
+    constexpr JobPlan<WHICH> JP{};
+    constexpr TrainPlan<WHICH> plan{};
+    constexpr TJob J = JP.j[JJ];
+    constexpr int s0 = JP.slot0[JJ];
+    if (wave != J.wave) return;
+    const int x = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < J.nt; ++k) {
+        constexpr int dummy = 0; (void)dummy;
+        const TrainPhase P = plan.p[J.ph[k]];
+        const bool rs = J.ch[k] < 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = 16 * J.rt + 4 * g + i;
+            const float v = acc[s0 + k][i];
+            if (o < P.rows) {
+                if (rs) { if (x == 0) g_dec[P.b_base + o] = v; }
+                else if (16 * J.ch[k] + x < P.cols_total) g_dec[P.w_base + o * P.ld + P.col0 + 16 * J.ch[k] + x] = v;
+            }
+        }
+    }
+}
+template <int WHICH, int... Is>
+__device__ __forceinline__ void pn_jobs_flush_all(float* __restrict__ g_dec, int wave, int lane, const f4* acc, std::integer_sequence<int, Is...>)
+{
+    (pn_job_flush<WHICH, Is>(g_dec, wave, lane, acc), ...);
 }
 
 template <int WHICH, bool RAYS>
@@ -635,6 +862,7 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
     float* smf = reinterpret_cast<float*>(smem);
     char* pn = reinterpret_cast<char*>(smf + PM_IMG_F);
     constexpr int PM = PM_ROWS * PN_RB;                  // plane M behind plane H
+    NSK_PH(28);
     float* scratch = smf + PM_IMG_F + wave * 1056;       // per-wave scatter scratch: plane H of rows 0..124 (G1, G2, XC, XH), all rewritten only after the next iteration's first barrier
     static_assert(8 * 1056 * 4 <= PM_E * PN_RB, "scatter scratch must end before the E rows");
     {
@@ -643,45 +871,70 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
         copy_image_to_lds<512>(smem + PM_IMG_FRAG_F / 4, src + MlpBwdImgH::P_WO / 4, (128 + 288) / 4);
     }
     __syncthreads();
+    NSK_PH(29);
     const h8* imgh = reinterpret_cast<const h8*>(smem);
-    const h8* gimg = reinterpret_cast<const h8*>(A.bimg16);          // e-part fragments stay in global memory
+    // The e-part fragments (W0e^T, W3e^T: 12 groups, 24 KB) have no room in LDS beside the panel.  Until round 3 every wave read them from L2 for
+    // every tile: 192 KB per iteration through the CU's vector cache, ~3 000 cycles of streaming in front of everything issued behind them
+    // (tools/exp_ph3.py).  Now the workgroup copies them ONCE per iteration into panel rows that are dead between layer 0's tiles and the next
+    // iteration (plane H of G2 / XC / XH, rows 32..127: 26 112 B): global loads issued before layer 0, LDS stores after its last barrier.
+    const f4* gimg_e = reinterpret_cast<const f4*>(A.bimg16) + (size_t)MlpBwdImgH::W0ET * 2 * 1024 / 16;      // groups 18..29, contiguous
+    constexpr int EIMG_F4 = 12 * 2 * 1024 / 16;                      // 1536 float4 = 3 per thread
+    static_assert(EIMG_F4 == 3 * 512 && EIMG_F4 * 16 <= (PM_E - PM_G2) * PN_RB, "e-part image: three float4 per thread, inside plane H of rows 32..127");
+    f4* eimg = reinterpret_cast<f4*>(pn + PM_G2 * PN_RB);
+    const h8* eimgh = reinterpret_cast<const h8*>(eimg);
     const float* Wo = smf + PM_IMG_FRAG_F;
     const float* Bm = Wo + 128;
 
-    f4 acc[plan.nslots];
+    constexpr JobPlan<WHICH> JP{};
+    f4 acc[JP.nslots];
 #pragma unroll
-    for (int k = 0; k < plan.nslots; ++k) acc[k] = (f4)(0.f);
+    for (int k = 0; k < JP.nslots; ++k) acc[k] = (f4)(0.f);
 
     const int ntasks = (A.M + 15) >> 4;
     const int iters = tiles_per_wave(ntasks, nb * 8, 0);
-    const bool scat = (A.flags & 1u) && A.grid.g;
-    struct Staged { float px, py, pz, zz; int n; bool valid; f4 gr; f4 xc[CQ]; f4 h4[2]; unsigned long long mask; } nx;
+    const bool scat = (A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9);
+    const bool no_put = NSK_DBG(A, 14), no_tiles = NSK_DBG(A, 13);      // experiment builds only (constant false otherwise); the barriers always stay
+    (void)no_put; (void)no_tiles;
+    // Staged: what iteration it + 1 needs, fetched during iteration it in three steps, none of which waits for a load it has just issued:
+    //   stage_a   (after the chain)        sample data as loaded (z, ray), upstream gradient, ReLU bits, h4   -- issue only
+    //   stage_b1  (before phase DB's barrier)  the point p, its cell, and the 16 corner loads of the gather    -- issue only
+    //   stage_b2  (after phase DB)         the trilinear reduction of those corners into xc
+    // (until round 3 stage_a computed p at once and stage_b reduced its gather at once: ~2 700 + ~5 000 cycles of an iteration spent
+    // waiting for round trips to L2 with nothing else to issue -- tools/exp_ph3.py)
+    struct Staged { SampleRaw r; float px, py, pz; int mm; bool valid; f4 gr; f4 xc[CQ]; f4 h4[2]; unsigned long long mask; } nx;
     auto task_of = [&](int it_) { return tile_of(it_, bid * 8 + wave, nb * 8, 0); };
     auto slot_of = [&](int it_) { return task_of(it_) * 16 + j; };
     auto stage_a = [&](int it_, int mm, Staged& S_) {
         const int task = task_of(it_);
         const int slot = task * 16 + j;
         S_.valid = slot < A.M;
-        sample_point(A, mm, S_.px, S_.py, S_.pz, S_.zz, S_.n);
+        S_.mm = mm;
+        sample_load(A, mm, S_.r);
         S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
         const int tk = min(task, ntasks - 1);
+        NSK_IDX(3, tk, ntasks); NSK_IDX(2, min(slot, A.M - 1), A.M);
         S_.mask = A.masks[(size_t)min(slot, A.M - 1) * 4 + g];
         S_.h4[0] = A.hsave[((size_t)tk * 10 + 8) * 64 + lane]; S_.h4[1] = A.hsave[((size_t)tk * 10 + 9) * 64 + lane];
     };
-    auto stage_b = [&](Staged& S_) {
-        Tri T_;
-        tri_setup(A.grid, A.bound, S_.px, S_.py, S_.pz, T_);
-        tri_gather(A.grid, T_, g, S_.xc[0], S_.xc[1]);
+    Tri Tn; GatherRaw GR;                                // the next tile's cell and its corner lines in flight
+    auto stage_b1 = [&](Staged& S_) {
+        sample_finish(A, S_.r, S_.px, S_.py, S_.pz);
+        tri_setup(A.grid, A.bound, S_.px, S_.py, S_.pz, Tn);
+        tri_gather_issue(A.grid, Tn, g, GR);
     };
+    auto stage_b2 = [&](Staged& S_) { tri_gather_reduce(Tn, GR, S_.xc[0], S_.xc[1]); };
     int mm_next = 0;
-    if (iters > 0) { stage_a(0, slot_sample(A, slot_of(0)), nx); stage_b(nx); mm_next = slot_sample(A, slot_of(1)); }
+    if (iters > 0) { stage_a(0, slot_sample(A, slot_of(0)), nx); stage_b1(nx); stage_b2(nx); mm_next = slot_sample(A, slot_of(1)); }
     asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
+    NSK_PH(30);
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
         lane = lane0; asm volatile("" : "+v"(lane)); j = lane & 15; g = lane >> 4;      // (see decode_bwd_train_body)
+        NSK_PH(0); NSK_PHI(0);
         if (it > 0) lds_barrier();                   // scratch (G1 / G2), XC and E are rewritten from here on
         const bool valid = nx.valid;
-        float px = nx.px, py = nx.py, pz = nx.pz, zz = nx.zz; const int n = nx.n;
+        float px = nx.px, py = nx.py, pz = nx.pz, zz = A.pts ? 0.f : nx.r.z; const int n = A.pts ? 0 : ray_of(A, nx.mm);
+        (void)zz; (void)n;
         float gout[OD];
         {
             f4 gr = nx.gr;
@@ -695,6 +948,7 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
         const float us = chain_scale<OD>(gout);
         const unsigned long long mask = nx.mask;
         const int htask = min(task_of(it), ntasks - 1);
+        NSK_IDX(3, htask, ntasks);
         f4 hq[5][2];                                      // block outputs h0..h4 as they are fetched
         hq[4][0] = nx.h4[0]; hq[4][1] = nx.h4[1];
         auto load_h = [&](auto KC) {
@@ -707,10 +961,11 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
             f4 xe[6], dummy[6];
             embed<false>(Bm, g, px, py, pz, xe, dummy);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) pn_put(pn, PM, PM_E + 16 * q, wave, lane, xe[q]);
+            for (int q = 0; q < 6; ++q) if (!no_put) pn_put(pn, PM, PM_E + 16 * q, wave, lane, xe[q]);
         }
-        pn_put(pn, PM, PM_XC, wave, lane, nx.xc[0]);
-        pn_put(pn, PM, PM_XC + 16, wave, lane, nx.xc[1]);
+        if (!no_put) pn_put(pn, PM, PM_XC, wave, lane, nx.xc[0]);
+        if (!no_put) pn_put(pn, PM, PM_XC + 16, wave, lane, nx.xc[1]);
+        NSK_PH(1); NSK_PHI(1);
         f4 gh[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -723,73 +978,78 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
             }
         // ---- phase OUT: G = g_out (rows >= OD zero), X = h4 --------------------------------------------------------------------
         {
-            pn_put(pn, PM, PM_G1, wave, lane, go);
-            pn_put(pn, PM, PM_XH, wave, lane, hq[4][0]);
-            pn_put(pn, PM, PM_XH + 16, wave, lane, hq[4][1]);
+            if (!no_put) pn_put(pn, PM, PM_G1, wave, lane, go);
+            if (!no_put) pn_put(pn, PM, PM_XH, wave, lane, hq[4][0]);
+            if (!no_put) pn_put(pn, PM, PM_XH + 16, wave, lane, hq[4][1]);
             lds_barrier();
-            constexpr TrainPhase P = plan.p[PL::P_OUT];
-            pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PM_XH, PM_G1);
+            if (!no_tiles) pn_phase_jobs<WHICH, JobPlan<WHICH>::PH_OUT>(pn, PM, wave, lane, acc);
             lds_barrier();
         }
+        NSK_PH(2); NSK_PHI(2);
         f4 gc[2] = {(f4)(0.f), (f4)(0.f)};
         H2 xa3, xa;
         auto layer = [&](auto LC) {
             constexpr int l = decltype(LC)::value;
             if constexpr (l >= 2) load_h(std::integral_constant<int, l - 2>{});      // a whole layer ahead (see decode_bwd_train_body)
+            // g_a = ReLU'(.) g_h: the same half-word masks give the fp16 pieces of g_a (the chain's next operand) from those of g_h and the
+            // bf16 panel pieces of g_a from the panel pieces of g_h -- one split each instead of two, no fp32 select
+            if constexpr (l == 2) NSK_PH(20);
+            const Mask4 RM = relu_mask_dwords(mask, l);
             {
                 const H2 xg = split_block_h(gh[0], gh[1]);
                 f4 gl[2] = {(f4)(0.f), (f4)(0.f)};
                 gemm_h(imgh, MlpBwdImgH::FT(l), lane, xg, gc, gl);               // g_c += fc[l]^T g_h
                 gc[0] += gl[0] * (1.f / NSK_H16_SCALE); gc[1] += gl[1] * (1.f / NSK_H16_SCALE);
+                xa = mask_block_h4(xg, RM);
             }
-            f4 ga[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
-            xa = split_block_h(ga[0], ga[1]);
             // ---- the layer's phase: dFc_l = g_h c^T (G1 x XC), dW_l = g_a x^T (G2 x XH or E) ------------------------------------
-            pn_put(pn, PM, PM_G1, wave, lane, gh[0], us);
-            pn_put(pn, PM, PM_G1 + 16, wave, lane, gh[1], us);
-            pn_put(pn, PM, PM_G2, wave, lane, ga[0], us);
-            pn_put(pn, PM, PM_G2 + 16, wave, lane, ga[1], us);
+            if constexpr (l == 2) NSK_PH(21);
+            if (!no_put) pn_put_masked(pn, PM, PM_G1, PM_G2, wave, lane, gh[0], us, RM.d[0], RM.d[1]);
+            if (!no_put) pn_put_masked(pn, PM, PM_G1 + 16, PM_G2 + 16, wave, lane, gh[1], us, RM.d[2], RM.d[3]);
             if constexpr (l >= 1) {
                 constexpr int k = l == 3 ? 2 : l - 1;                            // layer 3 reads e (its own rows) and h2
-                pn_put(pn, PM, PM_XH, wave, lane, hq[k][0]);
-                pn_put(pn, PM, PM_XH + 16, wave, lane, hq[k][1]);
+                if (!no_put) pn_put(pn, PM, PM_XH, wave, lane, hq[k][0]);
+                if (!no_put) pn_put(pn, PM, PM_XH + 16, wave, lane, hq[k][1]);
             }
+            if constexpr (l == 2) NSK_PH(22);
             lds_barrier();
-            {
-                // FC tiles: six per layer.  In the layers whose W phase has fourteen tiles (0, 3) they are dealt to waves 6, 7, 0..3 so that no
-                // wave gets more than three (W: waves 0..5 two, 6..7 one; W3H: waves 4..7)
-                constexpr TrainPhase PF = plan.p[PL::P_FC0 + l];
-                constexpr int rot = (l == 0 || l == 3) ? 2 : 0;
-                pn_tiles<PF.nslots>(pn, PM, PF.RT, PF.NC, PF.rowsum, (wave + rot) & 7, lane, acc + PF.slot0, PM_XC, PM_G1);
-                constexpr TrainPhase PW = plan.p[PL::P_W0 + l];
-                pn_tiles<PW.nslots>(pn, PM, PW.RT, PW.NC, PW.rowsum, wave, lane, acc + PW.slot0, (l == 0 || l == 3) ? PM_E : PM_XH, PM_G2);
-                if constexpr (l == 3) {
-                    constexpr TrainPhase P2 = plan.p[PL::P_W3H];
-                    pn_tiles<P2.nslots>(pn, PM, P2.RT, P2.NC, P2.rowsum, (wave + 4) & 7, lane, acc + P2.slot0, PM_XH, PM_G2);
-                }
-            }
+            if constexpr (l == 2) NSK_PH(23);
+            if (!no_tiles) pn_phase_jobs<WHICH, 1 + (4 - l)>(pn, PM, wave, lane, acc);       // dFc_l, dW_l (and their bias rows) as jobs: see JobPlan
+            if constexpr (l == 2) NSK_PH(24);
             lds_barrier();
+            if constexpr (l == 2) NSK_PH(25);
             if constexpr (l == 3) xa3 = xa;
             if constexpr (l >= 1) {
                 f4 ghn[2] = {(f4)(0.f), (f4)(0.f)}, ghl[2] = {(f4)(0.f), (f4)(0.f)};
                 gemm_h(imgh, MlpBwdImgH::WT(l), lane, xa, ghn, ghl);
                 gh[0] = ghn[0] + ghl[0] * (1.f / NSK_H16_SCALE); gh[1] = ghn[1] + ghl[1] * (1.f / NSK_H16_SCALE);
             }
+            if constexpr (l == 2) NSK_PH(26);
         };
         layer(std::integral_constant<int, 4>{});
+        NSK_PH(3); NSK_PHI(3);
         layer(std::integral_constant<int, 3>{});
+        NSK_PH(4); NSK_PHI(4);
         layer(std::integral_constant<int, 2>{});
+        NSK_PH(5); NSK_PHI(5);
         layer(std::integral_constant<int, 1>{});
+        NSK_PH(6); NSK_PHI(6);
+        f4 ecp[3];                                           // this thread's share of the e-part image, in flight across layer 0
+#pragma unroll
+        for (int u = 0; u < 3; ++u) ecp[u] = gimg_e[u * 512 + (int)threadIdx.x];
         layer(std::integral_constant<int, 0>{});
+        NSK_PH(7); NSK_PHI(7);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) eimg[u * 512 + (int)threadIdx.x] = ecp[u];      // rows 32..127 are dead since layer 0's last barrier
+        lds_barrier();
         f4 ge[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
-        gemm_e2_global(gimg, lane, xa3, xa, ge);            // g_e = W3e^T g_a3 + W0e^T g_a0 (still carries the sample's scale)
+        gemm_e2_lds(eimgh, lane, xa3, xa, ge);              // g_e = W3e^T g_a3 + W0e^T g_a0 (still carries the sample's scale)
+        // the next tile's sample data: issued (not waited for) behind the e-part fragments -- loads return in order, and in front of them
+        // these (scattered, often beyond L2) made the first product wait for their round trip -- and ahead of the cosines and panel stores below
         if (it + 1 < iters) { stage_a(it + 1, mm_next, nx); mm_next = slot_sample(A, slot_of(it + 2)); }
+        NSK_PH(8); NSK_PHI(8);
         gc[0] *= us; gc[1] *= us;
         float gp[3] = {0.f, 0.f, 0.f};
         Tri T;
@@ -805,14 +1065,19 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
             f4 pq;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
-            pn_put(pn, PM, PM_G1, wave, lane, pq, us);
+            if (!no_put) pn_put(pn, PM, PM_G1, wave, lane, pq, us);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) pn_put(pn, PM, PM_E + 16 * q, wave, lane, ge[q]);
+            for (int q = 0; q < 6; ++q) if (!no_put) pn_put(pn, PM, PM_E + 16 * q, wave, lane, ge[q]);
+            // the next tile's gather goes out here: its 16 corner lines travel while the workgroup meets at the barrier and runs the tiles
+            // (unconditional, like its reduction below: under `if (it + 1 < iters)` the compiler cannot tell that both run or neither, keeps the 64
+            // corner registers alive around the whole loop and spills 85 of them; in the last iteration nx still holds this tile's sample,
+            // so the extra gather reads valid lines and its result is never used)
+            stage_b1(nx);
             lds_barrier();
-            constexpr TrainPhase P = plan.p[PL::P_DB];
-            pn_tiles<P.nslots>(pn, PM, P.RT, P.NC, P.rowsum, wave, lane, acc + P.slot0, PM_E, PM_G1);
+            if (!no_tiles) pn_phase_jobs<WHICH, JobPlan<WHICH>::PH_DB>(pn, PM, wave, lane, acc);
             lds_barrier();
         }
+        NSK_PH(9); NSK_PHI(9);
         if constexpr (RAYS) {
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
@@ -849,23 +1114,22 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
                 }
             }
         }
-        if (it + 1 < iters) stage_b(nx);
+        stage_b2(nx);
         // every staged load must have landed before the first atomic below (see decode_bwd_train_body)
-        asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
+        asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next), "+v"(nx.xc[0]), "+v"(nx.xc[1]));
+        NSK_PH(10); NSK_PHI(10);
         if (scat) {
             if (A.flags & 0x8000u) {        // deterministic debug mode: see decode_bwd_body
                 for (int w = 0; w < 8; ++w) { if (wave == w) { scatter_tile(A.grid, T, gc, lane, valid, scratch); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } __syncthreads(); }
             } else scatter_tile(A.grid, T, gc, lane, valid, scratch);
         }
+        NSK_PH(11); NSK_PHI(11);
     }
-    // ---- single flush of this wave's output tiles (the wave rotations of the tiles above) ---------------------------------------
+    NSK_PH(12);
+    // ---- single flush of this wave's output tiles (job by job) ---------------------------------------
     float* slab = A.g_dec + (size_t)bid * ((plan_total<WHICH>() + 3) & ~3);
-#define NSK_FLUSHW(ID, W) if constexpr (plan.p[ID].nslots > 0) pn_flush<plan.p[ID].nslots>(slab, plan.p[ID], W, lane, acc + plan.p[ID].slot0);
-    NSK_FLUSHW(PL::P_OUT, wave)
-    NSK_FLUSHW(PL::P_FC0 + 0, (wave + 2) & 7) NSK_FLUSHW(PL::P_FC0 + 1, wave) NSK_FLUSHW(PL::P_FC0 + 2, wave) NSK_FLUSHW(PL::P_FC0 + 3, (wave + 2) & 7) NSK_FLUSHW(PL::P_FC0 + 4, wave)
-    NSK_FLUSHW(PL::P_W0 + 0, wave) NSK_FLUSHW(PL::P_W0 + 1, wave) NSK_FLUSHW(PL::P_W0 + 2, wave) NSK_FLUSHW(PL::P_W0 + 3, wave) NSK_FLUSHW(PL::P_W0 + 4, wave)
-    NSK_FLUSHW(PL::P_W3H, (wave + 4) & 7) NSK_FLUSHW(PL::P_DB, wave)
-#undef NSK_FLUSHW
+    pn_jobs_flush_all<WHICH>(slab, wave, lane, acc, std::make_integer_sequence<int, JobPlan<WHICH>::NJ>{});
+    NSK_PH(13);
 }
 
 // which body a trainable decoder's backward runs: the merged-phase form for the middle and colour decoders

@@ -60,3 +60,49 @@ class ShardedMapper:
                 allreduce_grads(self.backend.grad_slab(), self.group)
         self.backend.adam_step(lr)
         return gt_depth_max
+
+
+def _rccl_lib():
+    import ctypes as C
+    for name in ("librccl.so", "librccl.so.1"):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            pass
+    return None
+
+
+def rccl_comm_from_group(group=None):
+    """An RCCL communicator of the process group's ranks for the C-ABI exchange (nsk_allreduce_grads: pack -> ncclAllReduce -> unpack on
+    the context's stream, no Python between them): rank 0 draws the ncclUniqueId, the process group broadcasts its 128 bytes, every
+    rank calls ncclCommInitRank on its current device.  Returns the communicator as a ctypes void pointer, or None where that cannot
+    work (no process group, a CPU backend, librccl absent or an initialisation error) -- the caller then uses `allreduce_grads`."""
+    import ctypes as C
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_backend(group) != "nccl":
+        return None
+    lib = _rccl_lib()
+    if lib is None:
+        return None
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    uid = UniqueId()
+    ok = torch.ones(1, dtype=torch.int32, device="cuda")
+    if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+        ok.zero_()
+    t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device="cuda")
+    dist.broadcast(t, src=0, group=group)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok) == 0:
+        return None
+    C.memmove(C.byref(uid), bytes(t.cpu().tolist()), 128)
+    comm = C.c_void_p()
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rc = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    ok.fill_(1 if rc == 0 and comm.value else 0)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks take the same path
+    return comm if int(ok) == 1 else None

@@ -31,9 +31,15 @@ class Mapper {
     // not in the reference
     void set_frustum_mask(const std::string& grid_key, torch::Tensor mask_zyx);     // bool/uint8 [Z,Y,X]; undefined tensor = all
     void set_bound(torch::Tensor bound_3x2);
-    void seed(uint64_t s) { rng_seed = s; }
+    void seed(uint64_t s) { rng_seed = s; draw_calls = 0; }
+    // seed of the d-th pixel draw of this Mapper (d = 1, 2, ...: every keyframe_selection_overlap and every optimize_map call takes the next
+    // one, so no two calls draw the same pixels -- the reference draws fresh torch::randint pixels every call, utils.h:19-36)
+    static uint64_t draw_seed(uint64_t seed, uint64_t d) { return seed + 0xD1B54A32D192ED03ull * d; }
     float lr_factor;
     float last_loss = 0.f;
+    std::vector<float> last_losses;        // loss of every iteration of the last optimize_map call (downloaded once, after the loop)
+    int n_keyframes() const { return (int)keyframe_vector.size(); }
+    torch::Tensor keyframe_est_c2w(int k) const { return keyframe_vector.at((size_t)k).est_c2w; }      // (bundle adjustment rewrites these, :467-489)
     std::vector<float> last_overlap;       // overlap fraction of keyframes [0, n-1) in that call (empty if not ranked)
     std::vector<int> last_window;          // keyframe indices of the last optimize_map call (-1 = current frame)
     double last_iter_us = 0.0;             // mean wall time of one iteration of the last optimize_map loop (stream-synchronised at its end)
@@ -59,7 +65,7 @@ class Mapper {
     float w_color_loss;
     bool first_frame = true;
     bool user_mask[4] = {false, false, false, false};
-    uint64_t rng_seed = 0;
+    uint64_t rng_seed = 0, draw_calls = 0;
     struct Dev;                            // device-resident state of optimize_map: frame images, ray buffers, BA poses and their Adam moments
     std::shared_ptr<Dev> dev;
 };

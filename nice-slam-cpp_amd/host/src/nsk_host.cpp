@@ -461,10 +461,15 @@ struct DevArr {
 struct DevFrame {
     DevArr<float> depth, color;
     const void* key_d = nullptr; const void* key_c = nullptr; int64_t ver_d = -1, ver_c = -1;
+    // The key tensors are HELD: a (data_ptr, version) pair identifies an image only while its storage is alive.  The callers build a fresh
+    // from_blob(...).clone() per frame, the CPU allocator hands the freed address out again and a fresh clone starts at version 0, so
+    // an unheld key let frame k+1 pass for frame k (no upload, the previous frame optimised again, no error).
+    torch::Tensor hold_d, hold_c;
     int H = 0, W = 0;
     void set(const torch::Tensor& depth_t, const torch::Tensor& color_t)
     {
-        if (depth_t.data_ptr() == key_d && (int64_t)depth_t._version() == ver_d && color_t.data_ptr() == key_c && (int64_t)color_t._version() == ver_c) return;
+        if (hold_d.defined() && hold_c.defined() && depth_t.data_ptr() == key_d && (int64_t)depth_t._version() == ver_d &&
+            color_t.data_ptr() == key_c && (int64_t)color_t._version() == ver_c) return;
         torch::Tensor d = depth_t.detach().to(torch::kCPU, torch::kFloat32).contiguous();
         torch::Tensor c = color_t.detach().to(torch::kCPU, torch::kFloat32).contiguous();
         TORCH_CHECK(d.dim() == 2 && c.dim() == 3 && c.size(2) == 3 && c.size(0) == d.size(0) && c.size(1) == d.size(1), "frame images must be depth [H,W] and colour [H,W,3]");
@@ -472,6 +477,7 @@ struct DevFrame {
         depth.upload(d.data_ptr<float>(), (size_t)d.numel());
         color.upload(c.data_ptr<float>(), (size_t)c.numel());
         key_d = depth_t.data_ptr(); ver_d = (int64_t)depth_t._version(); key_c = color_t.data_ptr(); ver_c = (int64_t)color_t._version();
+        hold_d = depth_t; hold_c = color_t;              // (handles: no copy; they pin the storage, hence the address, until the next set)
     }
 };
 
@@ -716,7 +722,8 @@ void Mapper::keyframe_selection_overlap(torch::Tensor gt_color_, torch::Tensor g
     D.kf_pi.ensure(n); D.kf_pj.ensure(n); D.kf_ro.ensure(3 * n); D.kf_rd.ensure(3 * n); D.kf_gd.ensure(n);
     torch::Tensor pose = c2w.detach().to(torch::kCPU, torch::kFloat32).contiguous();
     D.poses.upload(pose.data_ptr<float>(), 12);
-    check(nsk_sample_pixels(ctx(), rng_seed + 0x9e3779b9ull * (uint64_t)(K + 1), n, 0, H, 0, W, D.kf_pi.p, D.kf_pj.p));        // get_samples(0,H,0,W,100,...) :137
+    const uint64_t call_seed = draw_seed(rng_seed, ++draw_calls);                             // a new draw every call (the reference: torch::randint)
+    check(nsk_sample_pixels(ctx(), call_seed + 0x9e3779b9ull * (uint64_t)(K + 1), n, 0, H, 0, W, D.kf_pi.p, D.kf_pj.p));        // get_samples(0,H,0,W,100,...) :137
     check(nsk_gather_pixels(ctx(), n, D.kf_pi.p, D.kf_pj.p, D.cur.H, D.cur.W, D.cur.depth.p, nullptr, D.kf_gd.p, nullptr));
     check(nsk_rays_from_pixels(ctx(), n, D.kf_pi.p, D.kf_pj.p, fx, fy, cx, cy, D.poses.p, 0, D.kf_ro.p, D.kf_rd.p));
     std::vector<float> poses((size_t)K * 16), pct((size_t)K);
@@ -794,10 +801,12 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     D.poses.upload(h_pose.data(), h_pose.size());
     D.cams.upload(h_cam.data(), h_cam.size());
     D.cam_m.zero((size_t)nf * 8); D.cam_v.zero((size_t)nf * 8);
-    D.rays.ensure((size_t)N); D.loss.ensure(4);
+    D.rays.ensure((size_t)N); D.loss.ensure((size_t)std::max(4, num_joint_iters_));           // one loss slot per iteration
     RayBufs& R = D.rays;
     const bool any_ba = BA && std::count(is_ba.begin(), is_ba.end(), 1) > 0;
     int ba_step = 0;
+    const uint64_t call_seed = draw_seed(rng_seed, ++draw_calls);                             // a new pixel stream every call (the reference draws
+                                                                                              // fresh torch::randint pixels, utils.h:19-36, Mapper.cpp:376-414)
     check(nsk_sync(ctx()));
     const double t0 = now_us();
     for (int joint_iter = 0; joint_iter < num_joint_iters_; ++joint_iter) {
@@ -821,7 +830,7 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
             const int f = optimize_frame[i];
             const DevFrame& F = f >= 0 ? *D.kf[f] : D.cur;
             frame_tab[i] = nsk_frame_rays{F.depth.p, F.color.p, is_ba[i] ? D.cams.p + 8 * i : D.poses.p + 12 * i, is_ba[i] ? 1 : 0,
-                                          rng_seed + 0x100000001b3ull * (uint64_t)(joint_iter * nf + i + 1)};
+                                          call_seed + 0x100000001b3ull * (uint64_t)(joint_iter * nf + i + 1)};
         }
         check(nsk_prepare_rays(ctx(), nf, frame_tab.data(), pixs_per_image, 0, H, 0, W, D.cur.H, D.cur.W, fx, fy, cx, cy, 0, R.pi.p, R.pj.p, R.gd.p, R.gc.p,
                                R.ro.p, R.rd.p, R.keep.p));                                    // :416-427 included: rays that leave the bound before their depth
@@ -830,7 +839,7 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
         // src/Mapper.cpp:430 renders the literal "color" whatever the stage (D19); the colour term of the loss follows `stage` (:438)
         const std::string render_stage = (render_stage_literal_color && !coarse_mapper) ? std::string("color") : stage;
         check(nsk_map_step(ctx(), nskh::stage_id(render_stage), N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, stage == "color" ? 1 : 0, flags,
-                           D.loss.p, nullptr, nullptr, nullptr, ba_now ? R.g_ro.p : nullptr, ba_now ? R.g_rd.p : nullptr));      // :430-444
+                           D.loss.p + joint_iter, nullptr, nullptr, nullptr, ba_now ? R.g_ro.p : nullptr, ba_now ? R.g_rd.p : nullptr));      // :430-444
         check(nsk_set_ray_mask(ctx(), nullptr));
         check(nsk_adam_step(ctx(), lr, 0.9f, 0.999f, 1e-8f));                                 // :445-446
         if (ba_now) {                                                                         // pose gradients through the ray generator and quad2rotation + Adam, per frame
@@ -845,7 +854,9 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     }
     check(nsk_sync(ctx()));
     last_iter_us = (now_us() - t0) / num_joint_iters_;
-    D.loss.download(&last_loss, 1);                                                           // the only per-call device-to-host traffic besides the results
+    last_losses.assign((size_t)num_joint_iters_, 0.f);
+    D.loss.download(last_losses.data(), (size_t)num_joint_iters_);                            // the only per-call device-to-host traffic besides the results
+    last_loss = last_losses.back();
     nskh::fetch_grids(c);                                                                     // :448-464 (once instead of per iteration)
     decoders.fetch_from_device(!fix_fine, !fix_color);
     if (any_ba) {                                                                             // :467-489

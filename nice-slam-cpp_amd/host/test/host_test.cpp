@@ -193,6 +193,53 @@ int main(int argc, char** argv)
             save_npy(out + "kf_overlap.npy", torch::tensor(mapper2.last_overlap));
             save_npy(out + "kf_poses.npy", torch::stack(poses));
         }
+        // ---- Mapper::run against the oracle (tests/test_gpu_host_cpp.py::test_mapper_run_matches_oracle_on_the_same_pixel_draws): six frames,
+        // every one a keyframe, so the last one optimises with bundle adjustment (more than four keyframes, :530); the stage schedule,
+        // lr_factor, overlap window, frustum masks, pixs_per_image and the BA pose update all come from the class.  Own grids and decoders.
+        {
+            std::string ns3 = NS_YAML;
+            ns3.replace(ns3.find("keyframe_every: 50"), 18, "keyframe_every: 1 ");
+            ns3.replace(ns3.find("lr_first_factor: 5"), 18, "lr_first_factor: 2");
+            ns3.replace(ns3.find("iters_first: 10"), 15, "iters_first: 4 ");
+            ns3.replace(ns3.find("  iters: 5\n  stage"), 10, "  iters: 3");
+            std::istringstream ns3_s(ns3);
+            YAML::Node nsc = YAML::Load(ns3_s);
+            if (nsc["mapping"]["iters"].as<int>() != 3 || nsc["mapping"]["iters_first"].as<int>() != 4 || nsc["tracking"]["iters"].as<int>() != 3) { std::fprintf(stderr, "mo yaml edit failed\n"); return 1; }
+            torch::manual_seed(21);
+            c10::Dict<std::string, torch::Tensor> c3;
+            c3.insert("grid_coarse", torch::zeros({1, 32, 3, 2, 4}).normal_(0, 0.3));
+            c3.insert("grid_middle", torch::zeros({1, 32, 6, 5, 7}).normal_(0, 0.3));
+            c3.insert("grid_fine", torch::zeros({1, 32, 9, 8, 11}).normal_(0, 0.3));
+            c3.insert("grid_color", torch::zeros({1, 32, 9, 8, 11}).normal_(0, 0.3));
+            NICE dec3(3, 32, 32, 2.f, 0.32f, 0.16f, 0.16f, true, "fourier");
+            for (auto k : {"grid_coarse", "grid_middle", "grid_fine", "grid_color"}) save_npy(out + "mo_" + k + "_0.npy", c3.at(k));
+            save_npy(out + "mo_dec_coarse.npy", dec3.coarse_decoder->packed()); save_npy(out + "mo_dec_middle.npy", dec3.middle_decoder->packed());
+            save_npy(out + "mo_dec_fine.npy", dec3.fine_decoder->packed()); save_npy(out + "mo_dec_color_0.npy", dec3.color_decoder->packed());
+            Mapper mo(nsc, cf, false);
+            mo.set_bound(bound);
+            mo.seed(4321);
+            auto roty = [&](float a) { torch::Tensor m = torch::eye(4); m[0][0] = std::cos(a); m[0][2] = std::sin(a); m[2][0] = -std::sin(a); m[2][2] = std::cos(a); return m; };
+            std::vector<torch::Tensor> est3;
+            for (float a : {0.0f, 0.10f, -0.08f, 0.15f, 0.05f, -0.04f}) {            // six nearby views of the same room (every window frame overlaps)
+                torch::Tensor p3 = torch::matmul(c2w.clone(), roty(a));
+                p3.index_put_({Slice(None, 3), 3}, c2w.index({Slice(None, 3), 3}) + torch::tensor({0.05f * a, 0.f, -0.1f * a}));
+                est3.push_back(p3);
+            }
+            save_npy(out + "mo_poses_0.npy", torch::stack(est3));
+            torch::Tensor losses = torch::full({6, 4}, -1.f), windows = torch::full({6, 6}, -9.f);
+            for (int idx = 0; idx < 6; ++idx) {
+                mo.run(dec3, c3, est3, color_img, depth_img, est3[idx], idx, 100);
+                for (size_t k = 0; k < mo.last_losses.size(); ++k) losses[idx][(int64_t)k] = mo.last_losses[k];
+                for (size_t k = 0; k < mo.last_window.size(); ++k) windows[idx][(int64_t)k] = (float)mo.last_window[k];
+            }
+            save_npy(out + "mo_losses.npy", losses); save_npy(out + "mo_windows.npy", windows);
+            for (auto k : {"grid_middle", "grid_fine", "grid_color"}) save_npy(out + "mo_" + k + "_1.npy", c3.at(k));
+            save_npy(out + "mo_dec_color_1.npy", dec3.color_decoder->packed());
+            save_npy(out + "mo_poses_1.npy", torch::stack(est3));                      // estimate_c2w_vec: the BA frame's entry is rewritten (:533)
+            std::vector<torch::Tensor> kfp;
+            for (int k = 0; k < mo.n_keyframes(); ++k) kfp.push_back(mo.keyframe_est_c2w(k));
+            save_npy(out + "mo_kf_poses_1.npy", torch::stack(kfp));
+        }
         // the renderer must see the optimised grids / decoder without any explicit upload
         renderer.render_batch_ray(c, decoders, rays_d, rays_o, "color", gt_depth, rgb, depth, var, weights);
         save_npy(out + "r3_depth.npy", depth); save_npy(out + "r3_rgb.npy", rgb);

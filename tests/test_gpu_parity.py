@@ -581,6 +581,51 @@ def test_graph_replay_matches_eager_steps(oracle32):
     assert abs(out["graph"][2] - out["eager"][2]) < 1e-4 * abs(out["eager"][2])
 
 
+def test_graph_is_refused_after_a_mask_change(oracle32):
+    """A captured step holds the optimiser masks' voxel lists as kernel arguments (k_adam_multi walks the marked voxels): new mask
+    CONTENTS must make nsk_graph_launch refuse the replay (it used to replay onto the old list silently), and a fresh capture must
+    equal the eager steps under the new mask"""
+    sc = _scene(27, grid_std=0.05)
+    rays = scenes.make_rays(28, 300, sc["bound"], n_frames=2)
+    ro, rd, gd, gc = cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"]), cu(rays["gt_color"])
+    lr = [0.005, 0.0, 0.005, 0.005, 0.005, 0.0]
+    rng = np.random.default_rng(5)
+    masks_a = {k: (rng.random(sc["grids"][k].shape[1:]) < 0.5).astype(np.uint8) for k in ("middle", "fine", "color")}
+    masks_b = {k: (1 - v).astype(np.uint8) for k, v in masks_a.items()}
+    out = {}
+    for mode in ("eager", "graph"):
+        ctx = make_ctx(sc, trainable=["color"])
+        loss = torch.zeros(1, device="cuda")
+        with torch.cuda.stream(ctx.tstream):
+            def step():
+                ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.2, True, flags=3, loss=loss)
+                ctx.adam_step(lr)
+            for k, v in masks_a.items():
+                ctx.set_mask(k, v)
+            step()
+            if mode == "graph":
+                ctx.graph_begin(); step(); gid = ctx.graph_end()
+                ctx.graph_launch(gid)
+            else:
+                step()
+            for k, v in masks_b.items():             # same allocation, new contents
+                ctx.set_mask(k, v)
+            if mode == "graph":
+                with pytest.raises(RuntimeError, match="stale"):
+                    ctx.graph_launch(gid)
+                step()                               # eager once (rebuilds the voxel lists), then capture again
+                ctx.graph_begin(); step(); gid2 = ctx.graph_end()
+                ctx.graph_launch(gid2)
+            else:
+                step(); step()
+        ctx.sync()
+        out[mode] = {k: ctx.grid_download(k) for k in ("middle", "fine", "color")}
+    for k in ("middle", "fine", "color"):
+        moved = np.abs(out["eager"][k] - sc["grids"][k]).max(axis=0)
+        assert (moved[masks_a[k] > 0] > 0).any() and (moved[masks_b[k] > 0] > 0).any()
+        assert rel_l2(out["graph"][k], out["eager"][k]) < 1e-5, k
+
+
 def test_fused_pose_kernels_equal_their_parts():
     """nsk_rays_from_camera = camera_from_tensor + rays_from_pixels and nsk_pose_step = rays_backward + camera_backward +
     adam_vector: same arithmetic, so the same bits (the parts are checked against the oracle in test_losses_and_pose_kernels)"""

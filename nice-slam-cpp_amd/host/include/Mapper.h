@@ -37,6 +37,7 @@ class Mapper {
     static uint64_t draw_seed(uint64_t seed, uint64_t d) { return seed + 0xD1B54A32D192ED03ull * d; }
     float lr_factor;
     float last_loss = 0.f;
+    std::vector<float> last_ba_grad;       // [window frames][7] pose gradients of the last bundle-adjustment step (zeros for frames it leaves fixed)
     std::vector<float> last_losses;        // loss of every iteration of the last optimize_map call (downloaded once, after the loop)
     int n_keyframes() const { return (int)keyframe_vector.size(); }
     torch::Tensor keyframe_est_c2w(int k) const { return keyframe_vector.at((size_t)k).est_c2w; }      // (bundle adjustment rewrites these, :467-489)

@@ -643,7 +643,7 @@ struct Mapper::Dev {
     std::vector<std::shared_ptr<DevFrame>> kf;           // keyframes, index = position in keyframe_vector
     RayBufs rays;
     DevArr<float> poses;                                 // [frames of the window][12] fixed c2w rows (3x4)
-    DevArr<float> cams, cam_m, cam_v;                    // BA: [frames][8] pose 7-vectors and their Adam moments
+    DevArr<float> cams, cam_m, cam_v, cam_g;             // BA: [frames][8] pose 7-vectors, their Adam moments and their last gradients
     DevArr<float> loss;
     DevArr<float> kf_ro, kf_rd, kf_gd;                   // the 100 overlap-ranking rays
     DevArr<int32_t> kf_pi, kf_pj;
@@ -800,7 +800,7 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     }
     D.poses.upload(h_pose.data(), h_pose.size());
     D.cams.upload(h_cam.data(), h_cam.size());
-    D.cam_m.zero((size_t)nf * 8); D.cam_v.zero((size_t)nf * 8);
+    D.cam_m.zero((size_t)nf * 8); D.cam_v.zero((size_t)nf * 8); D.cam_g.zero((size_t)nf * 8);
     D.rays.ensure((size_t)N); D.loss.ensure((size_t)std::max(4, num_joint_iters_));           // one loss slot per iteration
     RayBufs& R = D.rays;
     const bool any_ba = BA && std::count(is_ba.begin(), is_ba.end(), 1) > 0;
@@ -848,7 +848,7 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
                 if (!is_ba[i]) continue;
                 const size_t o = (size_t)i * pixs_per_image;
                 check(nsk_pose_step(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, fx, fy, cx, cy, 0, R.g_ro.p + 3 * o, R.g_rd.p + 3 * o, D.cams.p + 8 * i,
-                                    D.cam_m.p + 8 * i, D.cam_v.p + 8 * i, BA_cam_lr, 0.9f, 0.999f, 1e-8f, ba_step, nullptr));
+                                    D.cam_m.p + 8 * i, D.cam_v.p + 8 * i, BA_cam_lr, 0.9f, 0.999f, 1e-8f, ba_step, D.cam_g.p + 8 * i));
             }
         }
     }
@@ -859,7 +859,11 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     last_loss = last_losses.back();
     nskh::fetch_grids(c);                                                                     // :448-464 (once instead of per iteration)
     decoders.fetch_from_device(!fix_fine, !fix_color);
+    last_ba_grad.assign((size_t)nf * 7, 0.f);
     if (any_ba) {                                                                             // :467-489
+        std::vector<float> hg((size_t)nf * 8);
+        D.cam_g.download(hg.data(), hg.size());
+        for (int i = 0; i < nf; ++i) for (int k = 0; k < 7; ++k) last_ba_grad[(size_t)i * 7 + k] = hg[(size_t)i * 8 + k];
         D.cams.download(h_cam.data(), h_cam.size());
         torch::Tensor bottom = torch::tensor({{0.f, 0.f, 0.f, 1.f}});
         for (int i = 0; i < nf; ++i) {

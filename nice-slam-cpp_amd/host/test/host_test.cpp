@@ -233,6 +233,7 @@ int main(int argc, char** argv)
                 for (size_t k = 0; k < mo.last_window.size(); ++k) windows[idx][(int64_t)k] = (float)mo.last_window[k];
             }
             save_npy(out + "mo_losses.npy", losses); save_npy(out + "mo_windows.npy", windows);
+            save_npy(out + "mo_ba_grad.npy", torch::tensor(mo.last_ba_grad).reshape({-1, 7}));      // of the last frame's (only) BA step
             for (auto k : {"grid_middle", "grid_fine", "grid_color"}) save_npy(out + "mo_" + k + "_1.npy", c3.at(k));
             save_npy(out + "mo_dec_color_1.npy", dec3.color_decoder->packed());
             save_npy(out + "mo_poses_1.npy", torch::stack(est3));                      // estimate_c2w_vec: the BA frame's entry is rewritten (:533)

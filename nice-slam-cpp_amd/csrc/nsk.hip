@@ -726,6 +726,7 @@ struct nsk_ctx {
     bool median_fused_pending = false;
     int tune_no_fused_median = 0;           // 1: the Tracker's median threshold in its own launch even where the fused form applies (experiments, tests)
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
+    int tune_no_frozen_kernel = 0;          // 1: launches without a trainable role also go through k_decode_bwd_multi (experiments, tests)
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
     bool sorted = false;                    // the current step's decoder launches walk the samples in cell-sorted order (ws.perm)
@@ -849,6 +850,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     CHK(set_lds(k_median_thr, 16384 * 4));
     CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8, 2>, 160 * 1024));
     CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
+    CHK(set_lds(k_decode_bwd_frozen<false>, 160 * 1024));
     *out = c;
     return 0;
 }
@@ -920,6 +922,7 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
 {
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
+    if (!strcmp(key, "no_frozen_kernel")) { c->tune_no_frozen_kernel = value; return 0; }
     if (!strcmp(key, "no_fused_median")) { c->tune_no_fused_median = value; return 0; }
     if (!strcmp(key, "fwd_fine_cost")) { c->tune_fwd_fine_cost = value; return 0; }
     if (!strcmp(key, "fwd_color_cost")) { c->tune_fwd_color_cost = value; return 0; }
@@ -1818,13 +1821,19 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         return 0;
     }
     MA.n = n;
+    // no trainable role and no ray gradients (the fine / middle / coarse stages of the Mapper): the 16-wave frozen kernel (nsk_device.h); with ray
+    // gradients the frozen bodies need 160 VGPRs (the Tracker: 600 tiles, latency-bound either way) and stay in k_decode_bwd_multi
+    const bool frozen_only = train_role == -1 && !rays && !c->tune_no_frozen_kernel;
     if (train_role >= 0 && n > 1) split_wgs_train(c->num_cu, (M + 15) / 16, n, cost, train_role, MA.wg_end);
-    else split_wgs_balanced(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end);
+    else split_wgs_balanced(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end, frozen_only ? NSK_FROZEN_NW : 8);
     const int extra = d_loss ? 1 : 0;          // one more workgroup sums the per-ray losses written by k_composite
     if (d_loss) { MA.sum_src = c->ws.ray_loss; MA.sum_dst = d_loss; MA.sum_n = N; }
     {
         ProfScope ps(c, "decode_bwd_multi");
-        if (rays) k_decode_bwd_multi<true><<<MA.wg_end[n - 1] + extra, 512, lds, c->stream>>>(MA);
+        if (frozen_only) {
+            const size_t lds16 = lds - 8 * 3840 + (size_t)NSK_FROZEN_NW * 3840;      // image + one scatter scratch per wave
+            k_decode_bwd_frozen<false><<<MA.wg_end[n - 1] + extra, 64 * NSK_FROZEN_NW, lds16, c->stream>>>(MA);
+        } else if (rays) k_decode_bwd_multi<true><<<MA.wg_end[n - 1] + extra, 512, lds, c->stream>>>(MA);
         else k_decode_bwd_multi<false><<<MA.wg_end[n - 1] + extra, 512, lds, c->stream>>>(MA);
     }
     HIPCHK(hipGetLastError());

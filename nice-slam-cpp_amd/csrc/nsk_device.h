@@ -769,6 +769,7 @@ __device__ __forceinline__ void wave_skew(const DecArgs& A, int wave, int nw)
 
 // ray of sample mm = mm / S without the generic division (~25 vector instructions): umulhi by ceil(2^32 / S), exact for mm < 2^32 / S
 __device__ __forceinline__ int ray_of(const DecArgs& A, int mm) { return A.S_magic ? (int)__umulhi((unsigned)mm, A.S_magic) : mm; }
+struct __attribute__((packed, aligned(4))) Ray3 { float x, y, z; };
 __device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px, float& py, float& pz, float& zz, int& n)
 {
     if (A.pts) { px = A.pts[3 * mm]; py = A.pts[3 * mm + 1]; pz = A.pts[3 * mm + 2]; zz = 0.f; n = 0; return; }
@@ -776,9 +777,10 @@ __device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px
     n = ray_of(A, mm);           // = mm / A.S (the generic division is ~25 vector instructions)
     NSK_IDX(4, n, (A.M + A.S - 1) / A.S);
     zz = A.z[mm];
-    px = add_rn(A.rays_o[3 * n], mul_rn(A.rays_d[3 * n], zz));           // reference src/Renderer.cpp:121
-    py = add_rn(A.rays_o[3 * n + 1], mul_rn(A.rays_d[3 * n + 1], zz));
-    pz = add_rn(A.rays_o[3 * n + 2], mul_rn(A.rays_d[3 * n + 2], zz));
+    const Ray3 o = *reinterpret_cast<const Ray3*>(A.rays_o + 3 * n), d = *reinterpret_cast<const Ray3*>(A.rays_d + 3 * n);
+    px = add_rn(o.x, mul_rn(d.x, zz));           // reference src/Renderer.cpp:121
+    py = add_rn(o.y, mul_rn(d.y, zz));
+    pz = add_rn(o.z, mul_rn(d.z, zz));
 }
 
 // the same in two steps, for software pipelining: the loads (no arithmetic on their results) and the point.
@@ -788,6 +790,7 @@ __device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px
 // ReLUs within that of zero flip: K3 colour-grid gradient 3.5e-4 -> 1.15e-3 from the oracle, the very figure round 2's 32-bit addressing
 // experiment met; the index audit of tools/exp_idx.py is clean, so that discrepancy was this rounding effect, not an out-of-range read.)
 struct SampleRaw { float z, o[3], d[3]; };
+
 __device__ __forceinline__ void sample_load(const DecArgs& A, int mm, SampleRaw& R)
 {
     if (A.pts) { R.o[0] = A.pts[3 * mm]; R.o[1] = A.pts[3 * mm + 1]; R.o[2] = A.pts[3 * mm + 2]; R.z = 0.f; R.d[0] = R.d[1] = R.d[2] = 0.f; return; }
@@ -795,8 +798,11 @@ __device__ __forceinline__ void sample_load(const DecArgs& A, int mm, SampleRaw&
     const int n = ray_of(A, mm);     // = mm / A.S
     NSK_IDX(4, n, (A.M + A.S - 1) / A.S);
     R.z = A.z[mm];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { R.o[k] = A.rays_o[3 * n + k]; R.d[k] = A.rays_d[3 * n + k]; }
+    // a ray's origin and direction as ONE 12-byte load each (global_load_dwordx3 needs dword alignment only): the 16 samples of a cell-sorted tile
+    // come from 16 rays, so every load instruction touches 16 cache lines, and seven of them per tile and wave kept the CU's address unit busy
+    // for ~2 500 cycles of a trainable iteration (tools/exp_ph3.py: the stage_a segment); three do the same work
+    const Ray3 o = *reinterpret_cast<const Ray3*>(A.rays_o + 3 * n), d = *reinterpret_cast<const Ray3*>(A.rays_d + 3 * n);
+    R.o[0] = o.x; R.o[1] = o.y; R.o[2] = o.z; R.d[0] = d.x; R.d[1] = d.y; R.d[2] = d.z;
 }
 __device__ __forceinline__ void sample_finish(const DecArgs& A, const SampleRaw& R, float& px, float& py, float& pz)
 {
@@ -1269,7 +1275,7 @@ __device__ __forceinline__ void tri_grad_p(const GridD& G, const Tri& T, int g, 
 // [-> g_p for NSK_GRAD_RAYS: embedding and trilinear derivatives].  LDS holds the backward image.
 // Trainable decoders use decode_bwd_train_body (nsk_train.h).
 // ------------------------------------------------------------------------------------------------------
-template <int WHICH, bool RAYS>
+template <int WHICH, bool RAYS, int NW = 8>
 __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int nb)
 {
     constexpr bool XYZ = WHICH != 0;
@@ -1285,7 +1291,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     float* scratch = smf + IMG_F + wave * 960;                  // per-wave scatter scratch (3840 B)
     {
         const f4* src = B16 ? reinterpret_cast<const f4*>(A.bimg16) : A.bimg;
-        copy_image_to_lds<512>(smem, src, IMG_F / 4);
+        copy_image_to_lds<64 * NW>(smem, src, IMG_F / 4);
     }
     __syncthreads();
     const f4* bimg = smem;
@@ -1310,13 +1316,13 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         S_.mask = A.masks[(size_t)sl_ * 4 + g];
         S_.mm = mm_;
     };
-    const int nw = nb * 8, wg = bid * 8 + wave;
+    const int nw = nb * NW, wg = bid * NW + wave;
     const int tsh = tile_shift(ntasks, nw);
     const int kmax = tiles_per_wave(ntasks, nw, tsh);
     stage(tile_of(0, wg, nw, tsh), slot_sample(A, slot_of(tile_of(0, wg, nw, tsh))), nx);
     int mm_next = slot_sample(A, slot_of(tile_of(1, wg, nw, tsh)));
     const bool det = (A.flags & 0x8000u) != 0;      // deterministic debug mode: every wave walks all kmax rounds (they meet at barriers)
-    if (!det) wave_skew(A, wave, 8);
+    if (!det) wave_skew(A, wave, NW);
     for (int k = 0; k < kmax; ++k) {
         const int task = tile_of(k, wg, nw, tsh);
         if (task >= ntasks && !det) break;
@@ -1419,7 +1425,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
             tri_grad_p(A.grid, T, g, gc, gp);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { gp[k] += __shfl_xor(gp[k], 16); gp[k] += __shfl_xor(gp[k], 32); }
-            if (A.g_rays_o) for (int turn = 0; turn < (det ? 8 : 1); ++turn) {
+            if (A.g_rays_o) for (int turn = 0; turn < (det ? NW : 1); ++turn) {
                 if (det) { __syncthreads(); if (turn != wave) continue; }
                 // the 16 samples of a tile usually belong to one ray (S = 48 = 3 tiles): sum them in the wave and add once; sixteen
                 // lanes adding to one address serialise (200 rays: the ray-gradient atomics were most of a 74 us kernel)
@@ -1448,7 +1454,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         }
         if ((A.flags & 1u) && A.grid.g && !NSK_DBG(A, 9)) {
             if (det) {                      // deterministic debug mode (one workgroup): the waves scatter in turn, so every atomic add has a fixed place in time
-                for (int w = 0; w < 8; ++w) { if (wave == w) { scatter_tile(A.grid, T, gc, lane, valid, scratch); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } __syncthreads(); }
+                for (int w = 0; w < NW; ++w) { if (wave == w) { scatter_tile(A.grid, T, gc, lane, valid, scratch); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } __syncthreads(); }
             } else scatter_tile(A.grid, T, gc, lane, valid, scratch);
         }
     }
@@ -1456,3 +1462,23 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
 
 template <int WHICH, bool RAYS>
 __global__ __launch_bounds__(512) void k_decode_bwd(DecArgs A) { decode_bwd_body<WHICH, RAYS>(A, blockIdx.x, gridDim.x); }
+
+// A launch of FROZEN decoders only (the fine stage, the Tracker): their bodies need ~105 VGPRs, and inside k_decode_bwd_multi they inherit the
+// trainable body's ~240 and run at two waves per SIMD.  Here a workgroup is 16 waves (four per SIMD: two more tiles' latency chains -- scatter
+// fences, LDS round trips, MFMA dependencies -- to interleave) around one LDS image.
+#define NSK_FROZEN_NW 16
+template <bool RAYS>
+__global__ __launch_bounds__(64 * NSK_FROZEN_NW) void k_decode_bwd_frozen(MultiArgs MA)
+{
+    if (MA.sum_n > 0 && blockIdx.x == gridDim.x - 1) { block_sum(MA.sum_src, MA.sum_n, MA.sum_dst); return; }
+    int r = 0;
+    while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
+    const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];
+    const int bid = blockIdx.x - b0, nb = MA.wg_end[r] - b0;
+    switch (MA.which[r]) {
+    case 0: decode_bwd_body<0, RAYS, NSK_FROZEN_NW>(MA.a[r], bid, nb); break;
+    case 1: decode_bwd_body<1, RAYS, NSK_FROZEN_NW>(MA.a[r], bid, nb); break;
+    case 2: decode_bwd_body<2, RAYS, NSK_FROZEN_NW>(MA.a[r], bid, nb); break;
+    default: decode_bwd_body<3, RAYS, NSK_FROZEN_NW>(MA.a[r], bid, nb); break;
+    }
+}

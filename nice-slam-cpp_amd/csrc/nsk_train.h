@@ -768,6 +768,31 @@ struct JobPlan {
     }
 };
 
+// every output tile of the decoder's TrainPlan -- (phase, row tile, column chunk or row sums) -- must be owned by exactly one job
+template <int WHICH>
+constexpr bool jobplan_covers_plan()
+{
+    constexpr JobPlan<WHICH> JP{};
+    constexpr TrainPlan<WHICH> plan{};
+    for (int ph = 0; ph < TrainPlan<WHICH>::NPH; ++ph) {
+        const TrainPhase P = plan.p[ph];
+        for (int rt = 0; rt < P.RT; ++rt)
+            for (int ch = -1; ch < P.NC; ++ch) {
+                if (ch < 0 && !P.rowsum) continue;
+                int owners = 0;
+                for (int q = 0; q < JobPlan<WHICH>::NJ; ++q)
+                    for (int k = 0; k < JP.j[q].nt; ++k)
+                        if (JP.j[q].ph[k] == ph && JP.j[q].rt == rt && (ch < 0 ? JP.j[q].ch[k] < 0 : JP.j[q].ch[k] == ch)) ++owners;
+                if (owners != 1) return false;
+            }
+    }
+    int tiles = 0, want = 0;
+    for (int q = 0; q < JobPlan<WHICH>::NJ; ++q) tiles += JP.j[q].nt;
+    for (int ph = 0; ph < TrainPlan<WHICH>::NPH; ++ph) want += plan.p[ph].RT * plan.p[ph].NC + (plan.p[ph].rowsum ? plan.p[ph].RT : 0);
+    return tiles == want && JP.nslots <= 12;
+}
+static_assert(jobplan_covers_plan<1>() && jobplan_covers_plan<3>(), "JobPlan: a weight-gradient tile is unowned, owned twice, or a wave holds more than 12 tiles");
+
 template <int WHICH, int JJ>
 __device__ __forceinline__ void pn_job(const char* __restrict__ pn, int moff, int wave, int lane, f4* acc)
 {
@@ -909,12 +934,12 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
         const int slot = task * 16 + j;
         S_.valid = slot < A.M;
         S_.mm = mm;
-        sample_load(A, mm, S_.r);
-        S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+        if (!NSK_DBG(A, 10)) sample_load(A, mm, S_.r);                       // (experiment bits 10, 11, 15: which of these loads stalls the issue -- tools/exp_ph3.py)
+        if (!NSK_DBG(A, 11)) S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
         const int tk = min(task, ntasks - 1);
         NSK_IDX(3, tk, ntasks); NSK_IDX(2, min(slot, A.M - 1), A.M);
-        S_.mask = A.masks[(size_t)min(slot, A.M - 1) * 4 + g];
-        S_.h4[0] = A.hsave[((size_t)tk * 10 + 8) * 64 + lane]; S_.h4[1] = A.hsave[((size_t)tk * 10 + 9) * 64 + lane];
+        if (!NSK_DBG(A, 11)) S_.mask = A.masks[(size_t)min(slot, A.M - 1) * 4 + g];
+        if (!NSK_DBG(A, 15)) { S_.h4[0] = A.hsave[((size_t)tk * 10 + 8) * 64 + lane]; S_.h4[1] = A.hsave[((size_t)tk * 10 + 9) * 64 + lane]; }
     };
     Tri Tn; GatherRaw GR;                                // the next tile's cell and its corner lines in flight
     auto stage_b1 = [&](Staged& S_) {
@@ -1041,11 +1066,14 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
         NSK_PH(7); NSK_PHI(7);
 #pragma unroll
         for (int u = 0; u < 3; ++u) eimg[u * 512 + (int)threadIdx.x] = ecp[u];      // rows 32..127 are dead since layer 0's last barrier
+        NSK_PH(14); NSK_PHI(14);
         lds_barrier();
+        NSK_PH(15); NSK_PHI(15);
         f4 ge[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
         gemm_e2_lds(eimgh, lane, xa3, xa, ge);              // g_e = W3e^T g_a3 + W0e^T g_a0 (still carries the sample's scale)
+        NSK_PH(16); NSK_PHI(16);
         // the next tile's sample data: issued (not waited for) behind the e-part fragments -- loads return in order, and in front of them
         // these (scattered, often beyond L2) made the first product wait for their round trip -- and ahead of the cosines and panel stores below
         if (it + 1 < iters) { stage_a(it + 1, mm_next, nx); mm_next = slot_sample(A, slot_of(it + 2)); }

@@ -35,12 +35,20 @@ def report(tag, flags=3):
         d = np.diff(t, axis=2)
         tot = t[:, :, 11] - t[:, :, 0]
         print("  %-6s iteration %6d cycles: " % (itn, med(tot)) + " ".join("%s %d" % (names[k + 1], med(d[:, :, k])) for k in range(11)))
+    for itn, base in (("second", 64), ("last", 0)):
+        print("  %-6s iteration, after layer 0: e-image stores %d, barrier %d, e-part products %d, stage_a issue %d" %
+              (itn, med(ph[:, :, base + 14] - ph[:, :, base + 7]), med(ph[:, :, base + 15] - ph[:, :, base + 14]), med(ph[:, :, base + 16] - ph[:, :, base + 15]),
+               med(ph[:, :, base + 8] - ph[:, :, base + 16])))
     t = ph[:, :, 20:27]
     print("  layer 2 (last iteration): mask+FT %d, puts %d, barrier %d, tiles %d, barrier %d, WT %d   (per wave of wg 0, tiles: %s)" %
           tuple([med(t[:, :, k + 1] - t[:, :, k]) for k in range(6)] + [" ".join(str(int(x)) for x in (ph[0, :, 24] - ph[0, :, 23]))]))
     sys.stdout.flush()
 
 report("base")
+report("stage_a without the sample loads (z, ray)", 3 | (1 << 10))
+report("stage_a without g_raw and the ReLU bits", 3 | (1 << 11))
+report("stage_a without h4", 3 | (1 << 15))
+report("stage_a without any load but perm", 3 | (1 << 10) | (1 << 11) | (1 << 15))
 report("no scatter", 3 | (1 << 9))
 report("no tiles", 3 | (1 << 13))
 report("no puts", 3 | (1 << 14))

@@ -156,7 +156,9 @@ __device__ __forceinline__ int cell_index(int GX, int GY, int GZ, const float* b
 // registers and issues one atomic flush per cell run instead of one per sample and cell (global float atomics run at
 // ~1.3 TB/s chip-wide and bounded the backward: DESIGN.md section 4).
 // ------------------------------------------------------------------------------------------------------
-#define NSK_SAMPLE_RAYS 16          // rays (waves) per workgroup of k_sample
+#ifndef NSK_SAMPLE_RAYS
+#define NSK_SAMPLE_RAYS 8           // rays (waves) per workgroup of k_sample (16: 19.6 us at 5000 rays, 8: 18.1, 4: 20.9; 1000 rays: 11.5 / 10.6 / 12.3)
+#endif
 #define NSK_SAMPLE_TABLE 2048       // slots of its cell table (>= 2 x NSK_SAMPLE_RAYS x 64 keeps probing short)
 __global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int N, int S, const float* __restrict__ rays_o,
                                                 const float* __restrict__ rays_d, const float* __restrict__ gt_depth,

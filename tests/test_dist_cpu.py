@@ -88,9 +88,12 @@ class OracleBackend:
         s[:] = 0
 
 
-def _scene_and_rays():
+def _scene_and_rays(kind="small"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import scenes
+    if kind == "k4":                                                 # BASELINE configs[3] at its per-rank size: office0-class grids, two 1250-ray shards
+        sc = scenes.make_scene(71, scenes.grid_shapes_for(scenes.K4_BOUND), bound=scenes.K4_BOUND)
+        return sc, scenes.make_rays(72, 2500, sc["bound"], n_frames=5, up="z", **scenes.CAM_NICE_SLAM)
     sc = scenes.make_scene(5, scenes.SMALL_GRID_SHAPES, grid_std=0.1)
     rays = scenes.make_rays(6, 37, sc["bound"], n_frames=1)          # odd count: uneven shards
     return sc, rays
@@ -105,20 +108,21 @@ def _masks(sc):
     return {"middle": rng.random(sc["grids"]["middle"].shape[1:]) < 0.6, "fine": None, "color": rng.random(sc["grids"]["color"].shape[1:]) < 0.6}
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, kind="small", steps=2):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import nice_slam_cpp_amd.dist as nd
-    sc, rays = _scene_and_rays()
+    sc, rays = _scene_and_rays(kind)
     lo, hi = nd.shard_range(rays["rays_o"].shape[0], rank, world)
     be = OracleBackend(sc)
+    be.o.lib.nso_set_num_threads(4 if kind == "k4" else 1)
     be.masks = _masks(sc)
     mapper = nd.ShardedMapper(be)
     sl = slice(lo, hi)
     gmaxes = []
-    for _ in range(2):
+    for _ in range(steps):
         g = mapper.step("color", rays["rays_o"][sl], rays["rays_d"][sl], torch.tensor(rays["gt_depth"][sl]).numpy() if False else rays["gt_depth"][sl],
                         rays["gt_color"][sl], LR, gt_depth_max=nd.global_depth_max(torch.tensor(rays["gt_depth"][sl])))
         gmaxes.append(g)
@@ -152,3 +156,31 @@ def test_two_rank_sharded_mapping_equals_single_process(tmp_path):
     assert abs(float(r0["loss"]) - be.loss) < 1e-9 * abs(be.loss)
     mk = _masks(sc)
     assert np.array_equal(r0["color"][:, ~mk["color"]], sc["grids"]["color"][:, ~mk["color"]])      # unmarked voxels: never sent, never moved
+
+
+def test_two_rank_sharded_mapping_at_the_k4_shard_size(tmp_path):
+    """the same at BASELINE configs[3]'s per-rank size: the office0-class grids (src/main.cpp:34-75 for that bound), 1250 rays x 48 per rank, rank-identical
+    optimiser masks, one colour-stage step: the packed exchange (marked voxels + colour decoder + loss) and the replicated Adam step must leave both
+    ranks bit-identical and equal to the single-process step on the 2500 rays"""
+    sys.path.insert(0, ROOT)
+    import nice_slam_cpp_amd.dist as nd
+    out = str(tmp_path / "k4rank%d.npz")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out, "k4", 1), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    sc, rays = _scene_and_rays("k4")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 1250, 1250, 2500)
+    assert float(r0["gmax"]) == float(r1["gmax"]) == float(rays["gt_depth"].max())
+    for k in ("fine", "color", "dec"):
+        assert np.array_equal(r0[k], r1[k]), k
+    be = OracleBackend(sc)
+    be.o.lib.nso_set_num_threads(8)
+    be.masks = _masks(sc)
+    m = nd.ShardedMapper(be)
+    m.step("color", rays["rays_o"], rays["rays_d"], rays["gt_depth"], rays["gt_color"], LR, gt_depth_max=float(rays["gt_depth"].max()))
+    for k, ref in (("fine", be.grids["fine"]), ("color", be.grids["color"]), ("dec", be.decs["color"])):
+        assert np.abs(r0[k] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
+    assert abs(float(r0["loss"]) - be.loss) < 1e-9 * abs(be.loss)
+    mk = _masks(sc)
+    n_marked = int(mk["middle"].sum()) * 32 + sc["grids"]["fine"].size + int(mk["color"].sum()) * 32
+    assert be.grad_pack().numel() == n_marked + sc["decoders"]["color"].size + 1                 # what travels: marked voxels of the three levels, decoder, loss

@@ -223,3 +223,69 @@ def test_map_prepare_gives_the_unprepared_steps():
     for k in g0:
         assert rel_l2(g1[k] - sc["grids"][k], g0[k] - sc["grids"][k]) < 5e-3, k          # (Adam amplifies last-bit differences of the sums: see test_gpu_configs)
     assert rel_l2(d1, d0) < 1e-4
+
+
+def test_rccl_communicator_bootstrapped_from_a_process_group():
+    """nice-slam-cpp_amd/dist.py::rccl_comm_from_group (what bench.py does at N > 1: ncclUniqueId drawn by rank 0, its 128 bytes broadcast over the
+    process group, ncclCommInitRank per rank) on a one-rank "nccl" process group: the communicator must come back and nsk_allreduce_grads over it
+    must leave the step unchanged (one rank: the sum is the identity).  The N-rank form differs only in the broadcast having receivers."""
+    import socket
+    import torch.distributed as dist
+    import nice_slam_cpp_amd.dist as nd
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        comm = nd.rccl_comm_from_group()
+        assert comm is not None and comm.value
+        out = {}
+        for use in (False, True):
+            sc, ctx, (ro, rd, gd, gc), mk = _setup()
+            loss = torch.zeros(1, device="cuda")
+            with torch.cuda.stream(ctx.tstream):
+                ctx.profile_begin()
+                for _ in range(2):
+                    ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.5, True, flags=3, loss=loss)
+                    if use:
+                        ctx.allreduce_grads_rccl(comm)
+                    ctx.adam_step(LR)
+                prof = ctx.profile_end()
+            ctx.sync()
+            assert ("allreduce" in prof) == use                       # the collective alone is timed on the context's stream (nsk_allreduce_grads)
+            out[use] = ({k: ctx.grid_download(k) for k in ("middle", "fine", "color")}, ctx.decoder_download("color"))
+        for k in ("middle", "fine", "color"):
+            assert rel_l2(out[True][0][k], out[False][0][k]) < 1e-5
+        assert rel_l2(out[True][1], out[False][1]) < 1e-5
+        rccl = _rccl()
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_multi_rank_line_rehearsal(tmp_path):
+    """bench.py as the driver launches it at N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks on this one GPU
+    over gloo (NSK_BENCH_REHEARSE=1: numbers mean nothing, the code path is the N > 1 one): the line must carry the all-reduce time alone and
+    its message size, BASELINE configs[3] as a FIXED 10000-ray batch sharded over the ranks (strong scaling), configs[1], and the headline with
+    the pipeline setting flipped."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, NSK_BENCH_REHEARSE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rays", "600"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["rays_per_gpu"] == 600
+    assert out["allreduce_us"] > 0 and out["exchange_bytes"] > 0 and out["config"]["pipeline"] is True
+    ex = out["extras"]
+    assert set(ex) == {"K4_strong_10000_rays", "K2_color", "K3_pipeline_off"}
+    assert ex["K4_strong_10000_rays"]["scaling"] == "strong" and ex["K4_strong_10000_rays"]["rays_per_gpu"] == 5000
+    for k in ex:
+        assert ex[k]["allreduce_us"] > 0 and ex[k]["value"] > 0

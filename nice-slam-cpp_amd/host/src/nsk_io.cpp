@@ -86,13 +86,17 @@ Mat imread(const std::string& filename, int flags)
         const uint32_t len = be32(p);
         const std::string tag((const char*)&file[p + 4], 4);
         if (p + 12 + len > file.size()) return Mat();
-        if (tag == "IHDR") { W = be32(p + 8); H = be32(p + 12); bits = file[p + 16]; ctype = file[p + 17]; interlace = file[p + 20]; }
+        if (tag == "IHDR") {
+            if (len != 13) return Mat();                                                // (a shorter chunk would be read past its end)
+            W = be32(p + 8); H = be32(p + 12); bits = file[p + 16]; ctype = file[p + 17]; interlace = file[p + 20];
+        }
         else if (tag == "IDAT") idat.insert(idat.end(), file.begin() + p + 8, file.begin() + p + 8 + len);
         else if (tag == "IEND") break;
         p += 12 + len;
     }
     const int cn = ctype == 0 ? 1 : (ctype == 2 ? 3 : (ctype == 6 ? 4 : 0));
     if (!W || !H || !cn || interlace || !((bits == 8) || (bits == 16 && cn == 1))) return Mat();    // palette / gray+alpha / interlaced: unsupported
+    if (W > (1u << 15) || H > (1u << 15)) return Mat();                                   // a hostile header must not size the allocations below
     const size_t bpp = (size_t)cn * bits / 8, stride = (size_t)W * bpp;
     std::vector<unsigned char> raw;
     if (!inflate_all(idat, raw, (stride + 1) * H) || raw.size() != (stride + 1) * H) return Mat();
@@ -177,24 +181,35 @@ int LoadEXR(float** out_rgba, int* width, int* height, const char* filename, con
     for (;;) {
         if (!need(1)) { exr_err(err, "LoadEXR: truncated header"); return TINYEXR_ERROR_INVALID_DATA; }
         if (d[p] == 0) { ++p; break; }
-        std::string name((const char*)&d[p]); p += name.size() + 1;
-        std::string type((const char*)&d[p]); p += type.size() + 1;
+        // every header string must end inside the file
+        auto cstr = [&](size_t at, std::string& out_s) { const void* z = at < d.size() ? std::memchr(&d[at], 0, d.size() - at) : nullptr; if (!z) return false; out_s.assign((const char*)&d[at]); return true; };
+        std::string name, type;
+        if (!cstr(p, name)) { exr_err(err, "LoadEXR: unterminated attribute name"); return TINYEXR_ERROR_INVALID_DATA; }
+        p += name.size() + 1;
+        if (!cstr(p, type)) { exr_err(err, "LoadEXR: unterminated attribute type"); return TINYEXR_ERROR_INVALID_DATA; }
+        p += type.size() + 1;
         if (!need(4)) return TINYEXR_ERROR_INVALID_DATA;
         const int32_t size = i32(p); p += 4;
         if (size < 0 || !need((size_t)size)) { exr_err(err, "LoadEXR: truncated attribute"); return TINYEXR_ERROR_INVALID_DATA; }
         if (name == "channels") {
             size_t q = p;
             while (q < p + size && d[q] != 0) {
-                Chan c; c.name = std::string((const char*)&d[q]); q += c.name.size() + 1;
+                Chan c;
+                const void* z = std::memchr(&d[q], 0, p + size - q);          // the name must end inside the attribute
+                if (!z) { exr_err(err, "LoadEXR: unterminated channel name"); return TINYEXR_ERROR_INVALID_DATA; }
+                c.name = std::string((const char*)&d[q]); q += c.name.size() + 1;
+                if (q + 16 > p + size) { exr_err(err, "LoadEXR: truncated channel list"); return TINYEXR_ERROR_INVALID_DATA; }
                 c.type = i32(q); q += 16;                                   // pixel type, pLinear + 3 reserved, xSampling, ySampling
+                if (c.type < 0 || c.type > 2) { exr_err(err, "LoadEXR: unknown pixel type"); return TINYEXR_ERROR_INVALID_DATA; }
                 chans.push_back(c);
             }
-        } else if (name == "compression") comp = d[p];
-        else if (name == "dataWindow") { xmin = i32(p); ymin = i32(p + 4); xmax = i32(p + 8); ymax = i32(p + 12); }
+        } else if (name == "compression") { if (size < 1) return TINYEXR_ERROR_INVALID_DATA; comp = d[p]; }
+        else if (name == "dataWindow") { if (size < 16) return TINYEXR_ERROR_INVALID_DATA; xmin = i32(p); ymin = i32(p + 4); xmax = i32(p + 8); ymax = i32(p + 12); }
         p += size;
     }
-    const int W = xmax - xmin + 1, H = ymax - ymin + 1;
-    if (W <= 0 || H <= 0 || chans.empty()) { exr_err(err, "LoadEXR: missing dataWindow or channels"); return TINYEXR_ERROR_INVALID_DATA; }
+    const long long Wl = (long long)xmax - xmin + 1, Hl = (long long)ymax - ymin + 1;      // (in 64 bits: the window corners are arbitrary int32)
+    if (Wl <= 0 || Hl <= 0 || Wl > (1 << 15) || Hl > (1 << 15) || chans.empty() || chans.size() > 64) { exr_err(err, "LoadEXR: missing or implausible dataWindow / channels"); return TINYEXR_ERROR_INVALID_DATA; }
+    const int W = (int)Wl, H = (int)Hl;
     if (comp < 0 || comp > 3) { exr_err(err, "LoadEXR: only NONE, RLE, ZIPS and ZIP compression are supported"); return TINYEXR_ERROR_UNSUPPORTED_FORMAT; }
     const int lines_per_block = comp == 3 ? 16 : 1;
     const int nblocks = (H + lines_per_block - 1) / lines_per_block;
@@ -212,15 +227,18 @@ int LoadEXR(float** out_rgba, int* width, int* height, const char* filename, con
     }
     const bool single = chans.size() == 1 || std::count(slot.begin(), slot.end(), -1) == (long)chans.size();
     float* out = (float*)std::malloc((size_t)W * H * 4 * sizeof(float));
+    if (!out) { exr_err(err, "LoadEXR: out of memory"); return TINYEXR_ERROR_INVALID_DATA; }
     for (size_t i = 0; i < (size_t)W * H; ++i) { out[4 * i] = out[4 * i + 1] = out[4 * i + 2] = 0.f; out[4 * i + 3] = 1.f; }
     std::vector<unsigned char> buf, tmp;
     for (int b = 0; b < nblocks; ++b) {
         size_t q = (size_t)offs[b];
         if (q + 8 > d.size()) { std::free(out); exr_err(err, "LoadEXR: bad block offset"); return TINYEXR_ERROR_INVALID_DATA; }
-        const int y0 = i32(q) - ymin; const int32_t dsize = i32(q + 4); q += 8;
+        const long long y0l = (long long)i32(q) - ymin; const int32_t dsize = i32(q + 4); q += 8;      // (64 bits: the block's line number is arbitrary)
+        if (y0l < 0 || y0l >= H) { std::free(out); exr_err(err, "LoadEXR: bad block"); return TINYEXR_ERROR_INVALID_DATA; }
+        const int y0 = (int)y0l;
         const int nl = std::min(lines_per_block, H - y0);
         const size_t expect = row_bytes * nl;
-        if (dsize < 0 || q + dsize > d.size() || y0 < 0 || nl <= 0) { std::free(out); exr_err(err, "LoadEXR: bad block"); return TINYEXR_ERROR_INVALID_DATA; }
+        if (dsize < 0 || q + (size_t)dsize > d.size() || nl <= 0) { std::free(out); exr_err(err, "LoadEXR: bad block"); return TINYEXR_ERROR_INVALID_DATA; }
         if (comp == 0 || (size_t)dsize == expect) buf.assign(d.begin() + q, d.begin() + q + dsize);      // stored raw
         else {
             tmp.resize(expect);

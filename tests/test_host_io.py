@@ -223,11 +223,20 @@ def io_dump(tmp_path_factory):
     r = subprocess.run([EXE, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     out = {f[4:-4]: np.load(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("out_")}
-    return out, fx, ex, seq_fx
+    return out, fx, ex, seq_fx, d
+
+
+def test_readers_survive_truncated_and_corrupted_files(io_dump, tmp_path):
+    """the PNG / EXR readers under AddressSanitizer + UBSan on every truncation and thousands of byte corruptions of the valid fixtures: they must
+    fail cleanly (empty Mat / error code) or decode, never read out of bounds (make io_fuzz_asan; the run aborts on the first sanitizer report)"""
+    subprocess.check_call(["make", "-s", "-C", HOST, "io_fuzz_asan"])
+    r = subprocess.run([os.path.join(HOST, "io_fuzz_asan"), io_dump[4]], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1"))
+    assert r.returncode == 0 and "io_fuzz ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 def test_png_reader(io_dump):
-    out, fx, _, _ = io_dump
+    out, fx, _, _ = io_dump[:4]
     assert np.array_equal(out["rgb8"], fx["rgb8"][:, :, ::-1].astype(np.float32))            # OpenCV order: B,G,R
     assert np.array_equal(out["rgba8"], fx["rgba8"][:, :, [2, 1, 0, 3]].astype(np.float32))
     assert np.array_equal(out["gray8"], fx["gray8"].astype(np.float32))
@@ -236,7 +245,7 @@ def test_png_reader(io_dump):
 
 
 def test_exr_reader(io_dump):
-    out, _, ex, _ = io_dump
+    out, _, ex, _ = io_dump[:4]
     for k, (chans, comp) in ex.items():
         got = out[k]
         H, W = chans[0][2].shape
@@ -255,7 +264,7 @@ def test_exr_reader(io_dump):
 
 
 def test_remap_bilinear_zero_border(io_dump):
-    out, _, _, _ = io_dump
+    out, _, _, _ = io_dump[:4]
     src = (np.arange(12, dtype=np.float32) ** 2).reshape(3, 4)
     xs = [0.0, 1.5, 2.25, 3.0, -0.5, 3.5]
     ys = [0.0, 0.5, 1.75, 2.0, 1.0, 2.5]
@@ -273,7 +282,7 @@ def test_remap_bilinear_zero_border(io_dump):
 def test_cofusion_reader(io_dump):
     """include/inputs/CoFusionReader.h surface: frames 3 and 4 of a tiny sequence; depth = channel 0 of the EXR (D27), colour / 255 in
     OpenCV's B,G,R order (src/inputs/CoFusionReader.cpp:44-51 as written)"""
-    out, _, _, seq = io_dump
+    out, _, _, seq = io_dump[:4]
     for idx, (col, dep) in seq.items():
         assert np.array_equal(out["seq_depth%d" % idx], dep)
         assert np.allclose(out["seq_rgb%d" % idx], col[:, :, ::-1].astype(np.float32) / 255.0, atol=1e-7)

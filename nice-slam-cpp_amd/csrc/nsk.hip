@@ -726,6 +726,7 @@ struct nsk_ctx {
     bool median_fused_pending = false;
     int tune_no_fused_median = 0;           // 1: the Tracker's median threshold in its own launch even where the fused form applies (experiments, tests)
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
+    int tune_frozen_mid_pct = 100;          // the middle decoder's frozen tile against the fine one's, in percent (its level has 8x the samples per voxel: more same-line atomics)
     int tune_no_frozen_kernel = 0;          // 1: launches without a trainable role also go through k_decode_bwd_multi (experiments, tests)
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
@@ -923,6 +924,7 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
     if (!strcmp(key, "no_frozen_kernel")) { c->tune_no_frozen_kernel = value; return 0; }
+    if (!strcmp(key, "frozen_mid_pct")) { if (value < 10 || value > 1000) return fail("nsk_set_tuning: frozen_mid_pct out of range"); c->tune_frozen_mid_pct = value; return 0; }
     if (!strcmp(key, "no_fused_median")) { c->tune_no_fused_median = value; return 0; }
     if (!strcmp(key, "fwd_fine_cost")) { c->tune_fwd_fine_cost = value; return 0; }
     if (!strcmp(key, "fwd_color_cost")) { c->tune_fwd_color_cost = value; return 0; }
@@ -1804,7 +1806,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         MA.which[n] = w; MA.train[n] = train ? 1 : 0;
         // relative cost of one tile of a frozen role against one 8-tile iteration of the trainable role (= 1000)
         const int frozen_cost = c->tune_frozen_cost > 0 ? c->tune_frozen_cost : 205;
-        cost[n] = train ? 1000 : frozen_cost;
+        cost[n] = train ? 1000 : (w == 1 ? frozen_cost * c->tune_frozen_mid_pct / 100 : frozen_cost);
         lds = std::max(lds, bwd_lds_bytes(w, train));
         if (train) train_role = (train_role == -1 && w != 2) ? n : -2;     // -2: more than one trainable decoder, or the fine one (its
                                                                             // body is not part of k_decode_bwd_multi) -> separate launches below

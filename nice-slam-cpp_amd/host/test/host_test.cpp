@@ -135,6 +135,19 @@ int main(int argc, char** argv)
         tracker.run(decoders, color_img, depth_img, c2w, 1);               // a second frame: buffers and images are reused, nothing is reallocated
         std::printf("Tracker::run device-resident: %.1f us per iteration (%d iterations, %d rays)\n", tracker.last_run_us / 3.0, 3, 100);
 
+        // ---- frame identity: the device copy of a frame is keyed by its host tensors; a NEW frame must be uploaded even when the allocator hands
+        // its tensors the addresses the previous frame's (freed) tensors had -- the result for frame B must be that of a Tracker that never saw A
+        {
+            Tracker ta(ns, cf, c); ta.set_bound(bound); ta.seed(500);
+            { torch::Tensor dA = depth_img.clone(), cA = color_img.clone(); ta.run(decoders, cA, dA, c2w, 0); }      // A's tensors die here
+            const float loss_a = ta.last_losses[0];
+            torch::Tensor dB = (depth_img * 0.9f).clone(), cB = (color_img * 0.5f).clone();                            // same sizes: the freed blocks are the first candidates
+            ta.seed(500); ta.run(decoders, cB, dB, c2w, 1);
+            Tracker tb(ns, cf, c); tb.set_bound(bound); tb.seed(500);
+            tb.run(decoders, cB, dB, c2w, 0);
+            save_npy(out + "frame_identity.npy", torch::tensor({loss_a, ta.last_losses[0], tb.last_losses[0]}));
+        }
+
         // ---- Mapper::run (first frame: iters_first, lr_first_factor) then a second frame with a keyframe in the window
         Mapper mapper(ns, cf, false);
         mapper.set_bound(bound);

@@ -107,6 +107,13 @@ def test_tracker_run_matches_oracle_on_the_same_pixel_draws(dump, oracle32, orac
     assert e < 1e-4 or e64 < 2 * eo + 1e-4, (e, e64, eo)
 
 
+def test_a_new_frame_is_uploaded_whatever_addresses_its_tensors_have(dump):
+    """the device-resident frame cache (DevFrame, keyed by the host tensors): frame B run after frame A on the same Tracker -- A's tensors freed, B's
+    the same size, so the allocator may hand out A's addresses -- must give exactly what a Tracker that never saw A gives, and not A's result"""
+    loss_a, loss_b_after_a, loss_b_fresh = [float(x) for x in dump["frame_identity"]]
+    assert loss_b_after_a == loss_b_fresh and loss_b_after_a != loss_a, (loss_a, loss_b_after_a, loss_b_fresh)
+
+
 def test_thin_mapper_methods_of_the_reference_surface(dump, oracle32):
     """Mapper::get_mask_from_c2w(cv::Mat, ...) and Mapper::keyframe_selection_overlap(...) (include/Mapper.h:24-25) as thin methods"""
     bound, grids, decs = _scene(dump)

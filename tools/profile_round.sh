@@ -1,10 +1,10 @@
 #!/bin/bash
-# Evidence for profiles/: run on the GPU box from the repo root:  bash tools/profile_round.sh r02
+# Evidence for profiles/: run on the GPU box from the repo root:  bash tools/profile_round.sh r03
 # 1. rocprofv3 --kernel-trace --stats over bench.py's default command (kernel durations; bench.py's own HIP-event figures must agree)
 # 2. separate --pmc passes, kernel-trace only, as the MI355X guide prescribes: FETCH_SIZE, WRITE_SIZE -> <tag>_pmc_hbm.json;
 #    SQ passes (MFMA instructions / busy cycles, wave cycles, LDS bank conflicts, instruction-cache misses) -> <tag>_pmc_sq.json
 set -e
-TAG=${1:-r02x}
+TAG=${1:-r03x}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -27,7 +27,7 @@ while read -r line; do
 done <<'PASSES'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES
 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_SALU
+SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_SALU GRBM_GUI_ACTIVE
 PASSES
 python3 $R/tools/pmc_summarize.py $OUT/sq1 $OUT/sq2 $OUT/sq3 > $OUT/${TAG}_pmc_sq.json
 tail -c 600 $OUT/${TAG}_bench.json; echo; cat $OUT/${TAG}_pmc_hbm.json; head -c 3000 $OUT/${TAG}_pmc_sq.json

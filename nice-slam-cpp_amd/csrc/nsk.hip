@@ -71,6 +71,12 @@ __global__ void k_adam_multi(AdamArgs A)
     const int b0 = r == 0 ? 0 : A.s[r - 1].blk_end;
     int i = (blockIdx.x - b0) * blockDim.x + threadIdx.x;
     f4 extra = (f4)(0.f);
+    // a trainable decoder's parameters are walked 8 float4 per block; the thread that will update float4 `i` fetches everything that does not
+    // depend on the gradient -- moments, parameter, the image positions of its four parameters -- TOGETHER with the slab loads below: the launch was
+    // three dependent round trips (slabs -> moments / parameter -> index tables -> image stores), and its time is latency, not traffic
+    f4 pre_m = (f4)(0.f), pre_v = (f4)(0.f), pre_p = (f4)(0.f);
+    int pf[4] = {-1, -1, -1, -1}, pb[4] = {-1, -1, -1, -1}, p16[4] = {-1, -1, -1, -1}, ph[4] = {-1, -1, -1, -1};
+    bool pre = false;
     if (S.slabs) {      // decoder whose gradient still sits in per-workgroup slabs: 8 float4 per block, 32 thread groups sum 1/32 of the slabs each
         // (all of a thread's ~6 slab reads are in flight at once: this sum, not the grids' Adam traffic, was most of the launch's time --
         // 18 us with 8 groups reading ~24 slabs one after the other, 14 us with four reads in flight, see profiles/)
@@ -79,6 +85,18 @@ __global__ void k_adam_multi(AdamArgs A)
         i = (blockIdx.x - b0) * 8 + pi;
         f4 part = (f4)(0.f);
         if (4 * i < S.n) {
+            if (sg == 0) {
+                pre = true;
+                pre_m = reinterpret_cast<const f4*>(S.m)[i]; pre_v = reinterpret_cast<const f4*>(S.v)[i]; pre_p = reinterpret_cast<const f4*>(S.p)[i];
+                if (S.inv_f) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        pf[k] = S.inv_f[4 * i + k]; pb[k] = S.inv_b[4 * i + k];
+                        if (S.inv16) p16[k] = S.inv16[4 * i + k];
+                        if (S.invh) ph[k] = S.invh[4 * i + k];
+                    }
+                }
+            }
             const float* base = S.slabs + 4 * i;
 #pragma unroll 8
             for (int sl = sg; sl < S.nslabs; sl += 32) part += *reinterpret_cast<const f4*>(base + (size_t)sl * S.slab_stride);
@@ -96,11 +114,11 @@ __global__ void k_adam_multi(AdamArgs A)
     if (4 * i >= S.n) return;
     f4* g4 = reinterpret_cast<f4*>(S.g) + i;
     const f4 g0 = *g4;
-    f4 gg = g0 + extra, mm = reinterpret_cast<f4*>(S.m)[i], vv = reinterpret_cast<f4*>(S.v)[i];
+    f4 gg = g0 + extra, mm = pre ? pre_m : reinterpret_cast<f4*>(S.m)[i], vv = pre ? pre_v : reinterpret_cast<f4*>(S.v)[i];
     // a parameter that never received a gradient (g = m = v = 0) does not move under Adam: skip its five memory operations
     if (!S.inv_f && gg[0] == 0.f && gg[1] == 0.f && gg[2] == 0.f && gg[3] == 0.f && mm[0] == 0.f && mm[1] == 0.f && mm[2] == 0.f && mm[3] == 0.f &&
         vv[0] == 0.f && vv[1] == 0.f && vv[2] == 0.f && vv[3] == 0.f) return;
-    f4 pp = reinterpret_cast<f4*>(S.p)[i];
+    f4 pp = pre ? pre_p : reinterpret_cast<f4*>(S.p)[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         mm[k] = A.b1 * mm[k] + (1.f - A.b1) * gg[k];
@@ -113,16 +131,16 @@ __global__ void k_adam_multi(AdamArgs A)
     if (S.inv_f) {      // keep the MFMA fragment images of a trainable decoder in step with its parameters
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int fi = S.inv_f[4 * i + k], bi = S.inv_b[4 * i + k];
+            const int fi = pre ? pf[k] : S.inv_f[4 * i + k], bi = pre ? pb[k] : S.inv_b[4 * i + k];
             if (fi >= 0) S.fimg[fi] = pp[k];
             if (bi >= 0) S.bimg[bi] = pp[k];
             if (S.inv16) {
-                const int t = S.inv16[4 * i + k];
+                const int t = pre ? p16[k] : S.inv16[4 * i + k];
                 if (t >= 0) store_pieces(S.img16, t, pp[k], S.np16);
                 if (fi >= S.tail_off) S.img16_tail[fi - S.tail_off] = pp[k];
             }
             if (S.invh) {
-                const int t = S.invh[4 * i + k];
+                const int t = pre ? ph[k] : S.invh[4 * i + k];
                 if (t >= 0) store_pieces(S.imgh, t, pp[k], 2);
                 if (bi >= S.btail_off) S.imgh_tail[bi - S.btail_off] = pp[k];
             }

@@ -673,6 +673,27 @@ __device__ __forceinline__ void gemm_e2_lds(const h8* __restrict__ eimg, int lan
         acc[2 * a] = tH[0] + tL[0] * (1.f / NSK_H16_SCALE); acc[2 * a + 1] = tH[1] + tL[1] * (1.f / NSK_H16_SCALE);
     }
 }
+// The same product transposed: the chain's pieces as the A operand (rows = this wave's 16 samples), the fragment groups as B (columns = 16 embedding
+// features) -- the register contents of both are what gemm_e2_lds feeds the other way round.  acc[q][i] = g_e[feature 16q + (lane & 15)][sample
+// 4g + i]: the D layout then holds, per lane, one feature of four samples, which is the A operand of a 16 x 16 x 16 product over samples.
+__device__ __forceinline__ void gemm_e2T_lds(const h8* __restrict__ eimg, int lane, const H2& x3, const H2& x0, f4 (&acc)[6])
+{
+    constexpr int G3 = MlpBwdImgH::W3ET - MlpBwdImgH::W0ET;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const FragH f3 = load_frag_h(eimg, G3 + q, lane), f0 = load_frag_h(eimg, q, lane);
+        f4 tH = (f4)(0.f), tL = (f4)(0.f);
+        tH = mfma_h(x3.h, f3.h, tH); tL = mfma_h(x3.h, f3.l, tL); tL = mfma_h(x3.l, f3.h, tL);
+        tH = mfma_h(x0.h, f0.h, tH); tL = mfma_h(x0.h, f0.l, tL); tL = mfma_h(x0.l, f0.h, tL);
+        acc[q] = tH + tL * (1.f / NSK_H16_SCALE);
+    }
+}
+typedef short s4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mfma_bf16_k16(unsigned a01, unsigned a23, unsigned b01, unsigned b23, f4 c)
+{
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, (u2v){a01, a23}), __builtin_bit_cast(s4v, (u2v){b01, b23}), c, 0, 0, 0);
+}
 // (the loads of slice a + 1 are issued before the products of slice a: written slice by slice, every slice opened with a wait for an L2
 // round trip -- three of them, ~1 000 cycles each, per tile)
 struct FragE { FragH a30, a31, a00, a01; };
@@ -842,7 +863,7 @@ __device__ __forceinline__ void pn_phase_jobs(const char* __restrict__ pn, int m
     pn_jobs_seq<WHICH, JP.first[PH]>(pn, moff, wave, lane, acc, std::make_integer_sequence<int, JP.first[PH + 1] - JP.first[PH]>{});
 }
 // store the tiles of job JJ (if this wave owns it) into the workgroup's slab, canonical parameter layout
-template <int WHICH, int JJ>
+template <int WHICH, int JJ, bool SKIP_DB = false>
 __device__ __forceinline__ void pn_job_flush(float* __restrict__ g_dec, int wave, int lane, const f4* acc)
 {
     constexpr JobPlan<WHICH> JP{};
@@ -855,6 +876,7 @@ __device__ __forceinline__ void pn_job_flush(float* __restrict__ g_dec, int wave
     for (int k = 0; k < J.nt; ++k) {
         constexpr int dummy = 0; (void)dummy;
         const TrainPhase P = plan.p[J.ph[k]];
+        if (SKIP_DB && J.ph[k] == TrainPlan<WHICH>::P_DB) continue;       // (mapping steps keep d/dB outside the jobs: see the loop's tail)
         const bool rs = J.ch[k] < 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -867,10 +889,10 @@ __device__ __forceinline__ void pn_job_flush(float* __restrict__ g_dec, int wave
         }
     }
 }
-template <int WHICH, int... Is>
+template <int WHICH, bool SKIP_DB, int... Is>
 __device__ __forceinline__ void pn_jobs_flush_all(float* __restrict__ g_dec, int wave, int lane, const f4* acc, std::integer_sequence<int, Is...>)
 {
-    (pn_job_flush<WHICH, Is>(g_dec, wave, lane, acc), ...);
+    (pn_job_flush<WHICH, Is, SKIP_DB>(g_dec, wave, lane, acc), ...);
 }
 
 template <int WHICH, bool RAYS>
@@ -951,6 +973,8 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
     int mm_next = 0;
     if (iters > 0) { stage_a(0, slot_sample(A, slot_of(0)), nx); stage_b1(nx); stage_b2(nx); mm_next = slot_sample(A, slot_of(1)); }
     asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
+    f4 accB[2] = {(f4)(0.f), (f4)(0.f)};                // d loss / d B, this wave's tiles (see the loop's tail)
+    (void)accB;
     NSK_PH(30);
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
@@ -1069,41 +1093,92 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
         NSK_PH(14); NSK_PHI(14);
         lds_barrier();
         NSK_PH(15); NSK_PHI(15);
-        f4 ge[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
-        gemm_e2_lds(eimgh, lane, xa3, xa, ge);              // g_e = W3e^T g_a3 + W0e^T g_a0 (still carries the sample's scale)
-        NSK_PH(16); NSK_PHI(16);
-        // the next tile's sample data: issued (not waited for) behind the e-part fragments -- loads return in order, and in front of them
-        // these (scattered, often beyond L2) made the first product wait for their round trip -- and ahead of the cosines and panel stores below
-        if (it + 1 < iters) { stage_a(it + 1, mm_next, nx); mm_next = slot_sample(A, slot_of(it + 2)); }
-        NSK_PH(8); NSK_PHI(8);
         gc[0] *= us; gc[1] *= us;
         float gp[3] = {0.f, 0.f, 0.f};
         Tri T;
-        tri_setup(A.grid, A.bound, px, py, pz, T);
-        {
-            f4 e2[6], xcos[6];
-            embed<true>(Bm, g, px, py, pz, e2, xcos);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) ge[q] *= xcos[q];
-        }
-        // ---- phase DB: G = p (3 rows, times the unscale factor), X = g_s -----------------------------------------------------------
-        {
-            f4 pq;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
-            if (!no_put) pn_put(pn, PM, PM_G1, wave, lane, pq, us);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) if (!no_put) pn_put(pn, PM, PM_E + 16 * q, wave, lane, ge[q]);
-            // the next tile's gather goes out here: its 16 corner lines travel while the workgroup meets at the barrier and runs the tiles
-            // (unconditional, like its reduction below: under `if (it + 1 < iters)` the compiler cannot tell that both run or neither, keeps the 64
-            // corner registers alive around the whole loop and spills 85 of them; in the last iteration nx still holds this tile's sample,
-            // so the extra gather reads valid lines and its result is never used)
+        f4 ge[6];
+        if constexpr (!RAYS) {
+            // ---- d loss / d B without a panel phase (mapping steps: no ray gradients) ---------------------------------------------------
+            // dB[k][f] = sum_s us p_k[s] cos_f[s] g_e[f][s].  Until round 3 this was a seventh panel phase: g_s = g_e cos transposed through LDS
+            // (six put calls, 96 16-bit stores per lane), two barriers, six tiles.  The transposed e-part product leaves g_e with the D layout
+            // "one feature, four samples" per lane, which IS the A operand of v_mfma_f32_16x16x16_bf16; the cosines are computed in that layout
+            // (same arguments, same instructions: same values), and B = [us p] for the lane's (feature block, coordinate) column: the sums over
+            // the wave's 16 samples come out of 24 K=16 products per tile, accumulated over the wave's tiles in 8 registers, and the waves'
+            // partial sums meet once, in LDS, after the loop.  Column n = 3 (q mod 5) + k of accumulator q / 5 holds block q, coordinate k.
+            if (it + 1 < iters) { stage_a(it + 1, mm_next, nx); mm_next = slot_sample(A, slot_of(it + 2)); }
+            gemm_e2T_lds(eimgh, lane, xa3, xa, ge);
+            NSK_PH(16); NSK_PHI(16);
             stage_b1(nx);
-            lds_barrier();
-            if (!no_tiles) pn_phase_jobs<WHICH, JobPlan<WHICH>::PH_DB>(pn, PM, wave, lane, acc);
-            lds_barrier();
+            NSK_PH(8); NSK_PHI(8);
+            float* xch = reinterpret_cast<float*>(pn + PM + PM_G1 * PN_RB) + wave * 64;          // plane M of the G rows: dead since layer 0's tiles
+            if (g == 0) *reinterpret_cast<f4*>(xch + 4 * j) = (f4){px, py, pz, valid ? us : 0.f};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int nb3 = j / 3, nc = j - 3 * nb3;                                              // this lane's B column: feature block (mod 5), coordinate
+            unsigned ph01, pm01, ph23, pm23;
+            f4 sp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sp[i] = *reinterpret_cast<const f4*>(xch + 4 * (4 * g + i));
+            {
+                float pv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pv[i] = (nc == 0 ? sp[i][0] : (nc == 1 ? sp[i][1] : sp[i][2])) * sp[i][3];
+                split2_pair(pv[0], pv[1], ph01, pm01); split2_pair(pv[2], pv[3], ph23, pm23);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int f = 16 * q + j;
+                const float b0 = Bm[f], b1 = Bm[96 + f], b2 = Bm[192 + f];
+                float gs[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float s = add_rn(add_rn(mul_rn(sp[i][0], b0), mul_rn(sp[i][1], b1)), mul_rn(sp[i][2], b2));
+                    const float cv = __builtin_amdgcn_cosf(nsk_rev(s));
+                    gs[i] = f < NSK_E ? ge[q][i] * cv : 0.f;
+                }
+                unsigned ah01, am01, ah23, am23;
+                split2_pair(gs[0], gs[1], ah01, am01); split2_pair(gs[2], gs[3], ah23, am23);
+                const bool on = nb3 == (q % 5);
+                const unsigned bh01 = on ? ph01 : 0u, bh23 = on ? ph23 : 0u, bm01 = on ? pm01 : 0u, bm23 = on ? pm23 : 0u;
+                f4& d = accB[q / 5];
+                d = mfma_bf16_k16(ah01, ah23, bh01, bh23, d);
+                d = mfma_bf16_k16(ah01, ah23, bm01, bm23, d);
+                d = mfma_bf16_k16(am01, am23, bh01, bh23, d);
+                d = mfma_bf16_k16(am01, am23, bm01, bm23, d);
+            }
+            tri_setup(A.grid, A.bound, px, py, pz, T);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ge[q] = (f4)(0.f);
+            gemm_e2_lds(eimgh, lane, xa3, xa, ge);              // g_e = W3e^T g_a3 + W0e^T g_a0 (still carries the sample's scale)
+            NSK_PH(16); NSK_PHI(16);
+            // the next tile's sample data: issued (not waited for) behind the e-part fragments -- loads return in order, and in front of them
+            // these (scattered, often beyond L2) made the first product wait for their round trip -- and ahead of the cosines and panel stores below
+            if (it + 1 < iters) { stage_a(it + 1, mm_next, nx); mm_next = slot_sample(A, slot_of(it + 2)); }
+            NSK_PH(8); NSK_PHI(8);
+            tri_setup(A.grid, A.bound, px, py, pz, T);
+            {
+                f4 e2[6], xcos[6];
+                embed<true>(Bm, g, px, py, pz, e2, xcos);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) ge[q] *= xcos[q];
+            }
+            // ---- phase DB: G = p (3 rows, times the unscale factor), X = g_s -----------------------------------------------------------
+            {
+                f4 pq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { int row = 4 * g + i; pq[i] = !valid ? 0.f : (row == 0 ? px : (row == 1 ? py : (row == 2 ? pz : 0.f))); }
+                if (!no_put) pn_put(pn, PM, PM_G1, wave, lane, pq, us);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) if (!no_put) pn_put(pn, PM, PM_E + 16 * q, wave, lane, ge[q]);
+                // the next tile's gather goes out here: its 16 corner lines travel while the workgroup meets at the barrier and runs the tiles
+                // (unconditional, like its reduction below: under `if (it + 1 < iters)` the compiler cannot tell that both run or neither, keeps the 64
+                // corner registers alive around the whole loop and spills 85 of them; in the last iteration nx still holds this tile's sample,
+                // so the extra gather reads valid lines and its result is never used)
+                stage_b1(nx);
+                lds_barrier();
+                if (!no_tiles) pn_phase_jobs<WHICH, JobPlan<WHICH>::PH_DB>(pn, PM, wave, lane, acc);
+                lds_barrier();
+            }
         }
         NSK_PH(9); NSK_PHI(9);
         if constexpr (RAYS) {
@@ -1156,7 +1231,29 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
     NSK_PH(12);
     // ---- single flush of this wave's output tiles (job by job) ---------------------------------------
     float* slab = A.g_dec + (size_t)bid * ((plan_total<WHICH>() + 3) & ~3);
-    pn_jobs_flush_all<WHICH>(slab, wave, lane, acc, std::make_integer_sequence<int, JobPlan<WHICH>::NJ>{});
+    pn_jobs_flush_all<WHICH, !RAYS>(slab, wave, lane, acc, std::make_integer_sequence<int, JobPlan<WHICH>::NJ>{});
+    if constexpr (!RAYS) {
+        // d loss / d B: the eight waves' partial sums meet in LDS (the panel is dead), 128 lanes add them up and store [3][93]
+        __syncthreads();
+        f4* red = reinterpret_cast<f4*>(pn);
+        red[(wave * 2 + 0) * 64 + lane] = accB[0]; red[(wave * 2 + 1) * 64 + lane] = accB[1];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int a = threadIdx.x >> 6;
+            f4 v = red[a * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) v += red[(w * 2 + a) * 64 + lane];
+            constexpr TrainPhase P = plan.p[PL::P_DB];
+            const int q = a == 0 ? j / 3 : 5, k = j - 3 * (j / 3);
+            if (a == 0 ? j < 15 : j < 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = 16 * q + 4 * g + i;
+                    if (f < NSK_E) slab[P.w_base + k * P.ld + f] = v[i];
+                }
+            }
+        }
+    }
     NSK_PH(13);
 }
 

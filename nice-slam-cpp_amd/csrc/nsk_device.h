@@ -1276,6 +1276,25 @@ __device__ __forceinline__ void tri_grad_p(const GridD& G, const Tri& T, int g, 
 // g_out -> chain of transposed products -> g_c (-> run-deduplicated scatter into the grid gradient)
 // [-> g_p for NSK_GRAD_RAYS: embedding and trilinear derivatives].  LDS holds the backward image.
 // Trainable decoders use decode_bwd_train_body (nsk_train.h).
+// The same copy in two halves, so that a body can put the first tile's own loads between them: the image loads are issued, then the
+// sample loads (which wait only for the sample index fetched before the image: loads return in order), then the image is stored.
+// Until round 3 a body copied its image, met at the barrier and only then started the chain index -> sample -> corners: three round
+// trips behind the image's one (tools/exp_ph3.py: "first stage" 9 000 cycles after an image copy of 2 000).
+template <int K> struct ImgRegs { f4 v[K]; };
+template <int NT, int K>
+__device__ __forceinline__ void image_issue(ImgRegs<K>& R, const f4* __restrict__ src, int n4)
+{
+#pragma unroll
+    for (int u = 0; u < K; ++u) { const int i = u * NT + (int)threadIdx.x; R.v[u] = i < n4 ? src[i] : (f4)(0.f); }
+}
+template <int NT, int K>
+__device__ __forceinline__ void image_commit(f4* __restrict__ dst, const ImgRegs<K>& R, const f4* __restrict__ src, int n4)
+{
+#pragma unroll
+    for (int u = 0; u < K; ++u) { const int i = u * NT + (int)threadIdx.x; if (i < n4) dst[i] = R.v[u]; }
+    if (n4 > K * NT) copy_image_to_lds<NT>(dst + K * NT, src + K * NT, n4 - K * NT);
+}
+
 // ------------------------------------------------------------------------------------------------------
 template <int WHICH, bool RAYS, int NW = 8>
 __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int nb)
@@ -1291,11 +1310,9 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     float* scratch = smf + IMG_F + wave * 960;                  // per-wave scatter scratch (3840 B)
-    {
-        const f4* src = B16 ? reinterpret_cast<const f4*>(A.bimg16) : A.bimg;
-        copy_image_to_lds<64 * NW>(smem, src, IMG_F / 4);
-    }
-    __syncthreads();
+    const f4* img_src = B16 ? reinterpret_cast<const f4*>(A.bimg16) : A.bimg;
+    constexpr int IMG_K = (IMG_F / 4 + 64 * NW - 1) / (64 * NW) < 8 ? (IMG_F / 4 + 64 * NW - 1) / (64 * NW) : 8;
+    ImgRegs<IMG_K> img_regs;
     const f4* bimg = smem;
     const h8* img16 = reinterpret_cast<const h8*>(smem);
     const float* bimgf = reinterpret_cast<const float*>(smem);
@@ -1321,7 +1338,13 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     const int nw = nb * NW, wg = bid * NW + wave;
     const int tsh = tile_shift(ntasks, nw);
     const int kmax = tiles_per_wave(ntasks, nw, tsh);
-    stage(tile_of(0, wg, nw, tsh), slot_sample(A, slot_of(tile_of(0, wg, nw, tsh))), nx);
+    {
+        const int mm0 = slot_sample(A, slot_of(tile_of(0, wg, nw, tsh)));
+        image_issue<64 * NW>(img_regs, img_src, IMG_F / 4);
+        stage(tile_of(0, wg, nw, tsh), mm0, nx);
+        image_commit<64 * NW>(smem, img_regs, img_src, IMG_F / 4);
+        __syncthreads();
+    }
     int mm_next = slot_sample(A, slot_of(tile_of(1, wg, nw, tsh)));
     const bool det = (A.flags & 0x8000u) != 0;      // deterministic debug mode: every wave walks all kmax rounds (they meet at barriers)
     if (!det) wave_skew(A, wave, NW);

@@ -912,13 +912,7 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
     NSK_PH(28);
     float* scratch = smf + PM_IMG_F + wave * 1056;       // per-wave scatter scratch: plane H of rows 0..124 (G1, G2, XC, XH), all rewritten only after the next iteration's first barrier
     static_assert(8 * 1056 * 4 <= PM_E * PN_RB, "scatter scratch must end before the E rows");
-    {
-        const f4* src = reinterpret_cast<const f4*>(A.bimg16);
-        copy_image_to_lds<512>(smem, src, PM_IMG_FRAG_F / 4);
-        copy_image_to_lds<512>(smem + PM_IMG_FRAG_F / 4, src + MlpBwdImgH::P_WO / 4, (128 + 288) / 4);
-    }
-    __syncthreads();
-    NSK_PH(29);
+    // (the image copy itself sits further down, around the first tile's sample loads: image_issue, nsk_device.h)
     const h8* imgh = reinterpret_cast<const h8*>(smem);
     // The e-part fragments (W0e^T, W3e^T: 12 groups, 24 KB) have no room in LDS beside the panel.  Until round 3 every wave read them from L2 for
     // every tile: 192 KB per iteration through the CU's vector cache, ~3 000 cycles of streaming in front of everything issued behind them
@@ -971,7 +965,20 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
     };
     auto stage_b2 = [&](Staged& S_) { tri_gather_reduce(Tn, GR, S_.xc[0], S_.xc[1]); };
     int mm_next = 0;
-    if (iters > 0) { stage_a(0, slot_sample(A, slot_of(0)), nx); stage_b1(nx); stage_b2(nx); mm_next = slot_sample(A, slot_of(1)); }
+    {
+        const f4* src = reinterpret_cast<const f4*>(A.bimg16);
+        constexpr int K0 = (PM_IMG_FRAG_F / 4 + 511) / 512;
+        ImgRegs<K0> ir0; ImgRegs<1> ir1;
+        const int mm0 = slot_sample(A, slot_of(0));
+        image_issue<512>(ir0, src, PM_IMG_FRAG_F / 4);
+        image_issue<512>(ir1, src + MlpBwdImgH::P_WO / 4, (128 + 288) / 4);
+        if (iters > 0) stage_a(0, mm0, nx);
+        image_commit<512>(smem, ir0, src, PM_IMG_FRAG_F / 4);
+        image_commit<512>(smem + PM_IMG_FRAG_F / 4, ir1, src + MlpBwdImgH::P_WO / 4, (128 + 288) / 4);
+        __syncthreads();
+        NSK_PH(29);
+        if (iters > 0) { stage_b1(nx); stage_b2(nx); mm_next = slot_sample(A, slot_of(1)); }
+    }
     asm volatile("" : "+v"(nx.h4[0]), "+v"(nx.h4[1]), "+v"(nx.gr), "+v"(nx.mask), "+v"(mm_next));
     f4 accB[2] = {(f4)(0.f), (f4)(0.f)};                // d loss / d B, this wave's tiles (see the loop's tail)
     (void)accB;

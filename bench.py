@@ -215,7 +215,10 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
     ctx = pkg.Context(local)
     for kv in TUNE:                                  # --tune key=value: nsk_set_tuning experiments (include/nsk.h)
         k, v = kv.split("=")
-        ctx.set_tuning(k, int(v))
+        if k == "sort_mode":                             # (nsk_set_sort_mode: -1 automatic, 0 ray order, 1 cell-sorted)
+            ctx.set_sort_mode(int(v))
+        else:
+            ctx.set_tuning(k, int(v))
     ctx.set_render_opts()                                        # 32 + 16 samples (src/Renderer.cpp:9-10)
     if matmul_mode is not None:
         ctx.set_matmul_mode(matmul_mode)
@@ -246,10 +249,10 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
 
         def step(i):
             ro, rd, gd, gc, gmax = batches[i % len(batches)]
-            ctx.map_step(stage, ro, rd, gd, gc, gmax, w_color, stage == "color", flags=flags, loss=loss)
-            if pipeline and not graph:                           # the next batch's sampling + cell sort on the side stream, beside the exchange
-                nro, nrd, ngd, _, ngmax = batches[(i + 1) % len(batches)]
+            if pipeline and not graph:                           # the next batch is registered first: its sampling + cell sort ride in this step's
+                nro, nrd, ngd, _, ngmax = batches[(i + 1) % len(batches)]      # composite / backward / Adam launches (nsk_map_prepare)
                 ctx.map_prepare(stage, nro, nrd, ngd, ngmax, flags=flags)
+            ctx.map_step(stage, ro, rd, gd, gc, gmax, w_color, stage == "color", flags=flags, loss=loss)
             if world > 1:                                        # the one exchange of the path: the marked voxels of the touched levels,
                 if comm is not None:                             # the colour decoder's gradient and the loss
                     ctx.allreduce_grads_rccl(comm)               # pack -> ncclAllReduce -> unpack on the context's stream, no Python between them
@@ -395,12 +398,11 @@ def main():
     ap.add_argument("--rays", type=int, default=0, help="rays per GPU per step (0 = the workload's own count)")
     ap.add_argument("--stage", default="color")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the lines under 'extras' (K2, K4 shard, fine stage, operand modes; N > 1: K4 at 10000 rays / N, K2, pipeline flipped)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the lines under 'extras' (K2, K4 shard, fine stage, operand modes, pipeline flipped; N > 1: K4 at 10000 rays / N, K2, pipeline flipped)")
     ap.add_argument("--no-frustum-mask", action="store_true", help="optimise every voxel (mapping.frustum_feature_selection: False)")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step as a captured hipGraph (single GPU)")
-    ap.add_argument("--pipeline", type=int, default=-1, help="1: sample the next batch on the side stream (nsk_map_prepare) beside the exchange and the optimiser "
-                    "step; 0: off; -1 (default): off on one GPU (measured slower there: K3 0.521 against 0.501 ms), on for N > 1 where the exchange leaves the "
-                    "GPU idle -- the N > 1 run reports the other setting under extras")
+    ap.add_argument("--pipeline", type=int, default=-1, help="1: register the next batch before every step (nsk_map_prepare): its sampling rides in the step's composite "
+                    "launch, its cell sort in the backward and Adam launches; 0: every step samples its own batch first; -1 (default): on")
     ap.add_argument("--torch-exchange", action="store_true", help="N > 1: all-reduce the packed buffer through torch.distributed instead of nsk_allreduce_grads")
     ap.add_argument("--tune", action="append", default=[], help="key=value for nsk_set_tuning (experiments), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of each CPU baseline's timed sample")
@@ -432,7 +434,7 @@ def main():
             comm = nd.rccl_comm_from_group()                     # ncclUniqueId broadcast over the process group
             if comm is not None:
                 exchange = "nsk_allreduce_grads (pack -> ncclAllReduce -> unpack on the context's stream; RCCL communicator bootstrapped from the process group)"
-    pipeline = (world > 1) if args.pipeline < 0 else bool(args.pipeline)
+    pipeline = True if args.pipeline < 0 else bool(args.pipeline)
 
     W = workloads()
     wl = W[args.workload]
@@ -471,6 +473,9 @@ def main():
                                  "for the grid-gradient scatter",
                        "frustum_feature_selection": res["mask_frac"] is not None, "marked_voxel_fraction": res["mask_frac"],
                        "exchange": exchange, "pipeline": pipeline,
+                       "pipeline_detail": ("every timed step holds one batch's sampling + cell sort, forward, loss, backward and Adam; the sampling and sort are those of the "
+                                           "NEXT batch, registered before the step (nsk_map_prepare), and ride in this step's composite / backward / Adam launches "
+                                           "instead of three launches of their own in front of the forward") if pipeline else "every step samples and sorts its own batch first",
                        "parallelism": "rays sharded x%d, 1 all-reduce/step of %d floats (%.2f MB: marked voxels of the trained levels + colour decoder + loss; "
                                       "the dense gradient slab is %d floats)" % (world, res["exchange_floats"], 4e-6 * res["exchange_floats"], res["slab_floats"])},
             "roofline": head["roofline"], "step_rooflines": head["step_rooflines"], "kernels": head["kernels"], "final_loss": head["final_loss"],
@@ -488,7 +493,8 @@ def main():
                      ("K4_shard_color", "K4", "color", dict(N=W["K4"]["rays"]), 300),
                      ("K3_color_mode0", "K3", "color", dict(N=W["K3"]["rays"], matmul_mode=0), 100),
                      ("K3_color_mode1", "K3", "color", dict(N=W["K3"]["rays"], matmul_mode=1), 100),
-                     ("K3_color_no_mask", "K3", "color", dict(N=W["K3"]["rays"], frustum=False), 100)]
+                     ("K3_color_no_mask", "K3", "color", dict(N=W["K3"]["rays"], frustum=False), 100),
+                     ("K3_pipeline_%s" % ("off" if pipeline else "on"), "K3", "color", dict(N=W["K3"]["rays"], pipeline=not pipeline), 200)]
         else:
             plan += [("K4_strong_10000_rays", "K4", "color", dict(N=0, rays_total=10000), 300), ("K2_color", "K2", "color", dict(N=W["K2"]["rays"]), 300),
                      ("K3_pipeline_%s" % ("off" if pipeline else "on"), "K3", "color", dict(N=W["K3"]["rays"], pipeline=not pipeline), args.steps)]
@@ -498,7 +504,7 @@ def main():
             if world == 1 and wname == args.workload and stage == args.stage and n == N and not kw:
                 continue
             kw.setdefault("frustum", frustum)
-            kw.setdefault("pipeline", pipeline if world > 1 else False)
+            kw.setdefault("pipeline", pipeline)
             r = run_workload(W[wname], stage, n, k, 20, local, rank, world, dist, comm=comm, **kw)
             if rank != 0:
                 continue

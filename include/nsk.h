@@ -91,7 +91,8 @@ int nsk_set_sort_mode(nsk_ctx* ctx, int mode);
  *   "roctx" 1:         roctxRangePush/Pop around every launch group (names as in nsk_profile_end) for rocprofv3 --marker-trace;
  *   "frozen_cost" n:   relative cost of a frozen decoder's tile in the backward's workgroup split (0 = built-in value);
  *   "no_fused_median" 1: nsk_track_step computes the Tracker's median threshold in a launch of its own (composite, median, composite)
- *                      even where the one-launch form applies. */
+ *                      even where the one-launch form applies;
+ *   "no_piggyback" 1:  a batch registered with nsk_map_prepare is sampled by launches of its own at the start of its step. */
 int nsk_set_tuning(nsk_ctx* ctx, const char* key, int value);
 
 /* Scene bound [[x0,x1],[y0,y1],[z0,z1]]; the reference hard-codes it in five places
@@ -247,12 +248,15 @@ int nsk_camera_backward(nsk_ctx* ctx, const float* d_cam, const float* d_g_c2w, 
 /* inside-bbox pre-filter (src/Mapper.cpp:416-427, src/Tracker.cpp:48-58): d_keep[n] = (t >= gt_depth) */
 int nsk_inside_filter(nsk_ctx* ctx, int N, const float* d_rays_o, const float* d_rays_d, const float* d_gt_depth,
                       uint8_t* d_keep);
-/* Sampling (+ cell sort) of the NEXT batch on a side stream.  It starts when what is enqueued on the context's stream at the time of the
- * call has finished and runs beside what the caller enqueues afterwards (the gradient exchange, nsk_adam_step): call it right after the
- * nsk_map_step of the current batch with the arguments the next nsk_map_step will get (same device pointers, same gt_depth_max, same
- * flags, the same ray mask installed).  That nsk_map_step then finds its samples prepared and skips its own sampling launches; any
- * other call simply samples as usual (a prepared set that is never asked for is dropped).  The rays must not depend on the running
- * step's result (bundle adjustment moves poses: do not prepare then).  Results are those of the unprepared step. */
+/* Registers the NEXT batch, so that its sampling and cell sort leave the front of its own step: call it BEFORE the nsk_map_step of the current
+ * batch, with the arguments the next nsk_map_step will get (same device pointers, same gt_depth_max, same flags, the next batch's ray mask
+ * installed while you call it, the same render options and seed).  Nothing is launched by this call.  The nsk_map_step that follows carries
+ * the registered batch's sampling in its composite launch, its backward launch carries the offsets of the cell sort and the nsk_adam_step
+ * after it the placement; the next nsk_map_step finds its samples ready and starts with the forward.  Whatever has not been carried by then
+ * (the call came after the step, another call needed the cell histogram in between, gt_depth_max < 0 with more than 8192 rays, a graph
+ * capture) is launched at that point, as for an unprepared batch; a registered batch that is never asked for is dropped.  The rays and
+ * the ground truth must stay valid and unchanged until their step has run, and must not depend on the running step's result (bundle
+ * adjustment moves poses: do not prepare then).  Results are those of the unprepared step.  Everything runs on the context's stream. */
 int nsk_map_prepare(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d, const float* d_gt_depth, float gt_depth_max,
                     unsigned flags);
 

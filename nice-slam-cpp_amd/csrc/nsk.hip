@@ -61,10 +61,12 @@ struct AdamSeg { float* p; float* g; float* m; float* v; const int* idx; int nid
                  const int* inv16; unsigned short* img16; float* img16_tail; int tail_off; int np16;
                  const int* invh; unsigned short* imgh; float* imgh_tail; int btail_off;      // fp16 backward image (MlpBwdImgH) and its fp32 tail
                  const float* slabs; int nslabs, slab_stride; };                      // pending per-workgroup gradient slabs (k_decode_bwd_multi)   // bf16 3-piece image (nsk_bf16.h), its fp32 tail
-struct AdamArgs { AdamSeg s[8]; int n; float b1, b2, eps; };
+struct AdamArgs { AdamSeg s[8]; int n; float b1, b2, eps;
+                  PlaceArgs place; int adam_blocks; };       // optional (place.nblocks > 0): the NEXT batch's cell-sort placement rides behind the segments (nsk_map_prepare)
 // all parameter groups of one optimiser step in one launch (3 grid levels + trainable decoders)
 __global__ void k_adam_multi(AdamArgs A)
 {
+    if (A.place.nblocks > 0 && (int)blockIdx.x >= A.adam_blocks) { sort_place_body(A.place, (int)blockIdx.x - A.adam_blocks); return; }
     int r = 0;
     while (r < A.n - 1 && (int)blockIdx.x >= A.s[r].blk_end) ++r;
     const AdamSeg& S = A.s[r];
@@ -749,12 +751,12 @@ struct nsk_ctx {
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
     bool sorted = false;                    // the current step's decoder launches walk the samples in cell-sorted order (ws.perm)
-    // nsk_map_prepare: the sampling (+ cell sort) of the NEXT batch on a side stream, concurrent with the current step
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_prep_done = nullptr, ev_alt_free = nullptr;
-    bool prep_outstanding = false;
+    // nsk_map_prepare: the sampling (+ cell sort) of the NEXT batch rides in the launches of the current step (composite + sample, backward + scan,
+    // Adam + place): `req` is a registered batch nothing has been launched for yet, `prep` the batch whose outputs sit (or are being built) in the
+    // workspace's second set; done: bit 0 sampled, 1 offsets scanned, 2 placed
     struct Prep { bool valid = false; int stage = 0, N = 0, S = 0; const float* ro = nullptr; const float* rd = nullptr; const float* gt = nullptr;
-                  float gtmax = 0.f; const uint8_t* mask = nullptr; bool sorted = false; } prep;
+                  float gtmax = 0.f; const uint8_t* mask = nullptr; bool sorted = false; int done = 0; RParams R; } prep, req;
+    int tune_no_piggyback = 0;              // 1: a prepared batch is sampled by launches of its own at the start of its step (experiments, tests)
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
     int matmul_mode = 2;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split, 2 fp16 2-piece split (nsk_bf16.h)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
@@ -868,8 +870,8 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
 #undef SETB
     CHK(set_lds(k_median_thr, 16384 * 4));
     CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8, 2>, 160 * 1024));
-    CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));
-    CHK(set_lds(k_decode_bwd_frozen<false>, 160 * 1024));
+    CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024 - 256)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));      // (<false>, frozen: the scan role keeps a few words of static LDS)
+    CHK(set_lds(k_decode_bwd_frozen<false>, 160 * 1024 - 256));
     *out = c;
     return 0;
 }
@@ -897,7 +899,6 @@ extern "C" int nsk_ctx_destroy(nsk_ctx* c)
         hipFree(c->dec[i].fimg16); hipFree(c->dec[i].fidx16);
     }
     hipFree(c->xbuf); hipFree(c->slab); hipFree(c->d_bound); hipFree(c->scal); hipFree(c->fr_tmp);
-    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); hipEventDestroy(c->ev_prep_done); hipEventDestroy(c->ev_alt_free); }
     free_ws(c->ws);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -942,6 +943,7 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
     if (!strcmp(key, "no_frozen_kernel")) { c->tune_no_frozen_kernel = value; return 0; }
+    if (!strcmp(key, "no_piggyback")) { c->tune_no_piggyback = value; return 0; }
     if (!strcmp(key, "frozen_mid_pct")) { if (value < 10 || value > 1000) return fail("nsk_set_tuning: frozen_mid_pct out of range"); c->tune_frozen_mid_pct = value; return 0; }
     if (!strcmp(key, "no_fused_median")) { c->tune_no_fused_median = value; return 0; }
     if (!strcmp(key, "fwd_fine_cost")) { c->tune_fwd_fine_cost = value; return 0; }
@@ -1321,14 +1323,14 @@ extern "C" int nsk_decoder_set_trainable(nsk_ctx* c, int w, int t)
 }
 
 // ---- workspace --------------------------------------------------------------------------------------------
+static int prep_drop(nsk_ctx* c);
 static int ensure_ws(nsk_ctx* c, int N, int M)
 {
     Workspace& w = c->ws;
     if (M <= w.capM && N <= w.capN) return 0;
     if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));
-    c->prep.valid = false; c->prep_outstanding = false;
+    CHK(prep_drop(c));
     invalidate_graphs(c);
     int capM = std::max(M, w.capM), capN = std::max(N, w.capN);
     free_ws(w);
@@ -1355,8 +1357,7 @@ static int ensure_hist(nsk_ctx* c, size_t bins)
     if (bins <= w.hist_cap) return 0;
     if (c->capturing) return fail("graph capture: the workspace must grow (run the same step once before nsk_graph_begin)");
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));
-    c->prep.valid = false; c->prep_outstanding = false;
+    c->prep.valid = false; c->req.valid = false;       // (the histogram is replaced: nothing to clean)
     invalidate_graphs(c);
     if (w.hist) hipFree(w.hist - 16);
     hipFree(w.offs);
@@ -1644,63 +1645,112 @@ static bool sort_pays(nsk_ctx* c, int stage, int M, unsigned flags)
 }
 
 // sorted: the decoders of this step (forward and the backward that follows) walk the samples cell by cell (see k_sample)
-// sampling (+ cell sort) of one batch into the given output set, on the given stream
-static int launch_sampling(nsk_ctx* c, hipStream_t st, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax,
-                           const uint8_t* mask, bool sorted, float* z, int* skey, int* srank, int* offs, int* perm, float* gmax_slot, bool prof)
+static int stage_key_level(int stage)
 {
-    const int M = N * S;
     int key_level = 0;
     for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) key_level = STAGE_DEC[stage][q];      // the finest level the stage reads
-    const GridState& KG = c->grid[key_level];
+    return key_level;
+}
+static void samp_args(nsk_ctx* c, SampArgs& A, const RParams& R, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax,
+                      const float* gmax_dev, const uint8_t* mask, bool sorted, float* z, int* skey, int* srank)
+{
+    const GridState& KG = c->grid[stage_key_level(stage)];
     const GridState* PG = stage >= 2 ? &c->grid[1] : nullptr;      // parent level whose cells order the samples inside a key cell (k_sample)
     const size_t bins = KG.n / 32 * 8;
-    const float* gmax_dev = nullptr;
-    if (gt && gtmax < 0.f && N > 8192) {        // smaller batches: k_sample's waves take the maximum themselves
-        ProfScope ps(c, "depth_max", prof);
-        k_depth_max<<<1, 1024, 0, st>>>(N, gt, mask, gmax_slot);
-        gmax_dev = gmax_slot;
+    memset(&A, 0, sizeof(A));
+    A.R = R; A.N = N; A.S = S; A.rays_o = ro; A.rays_d = rd; A.gt_depth = gt; A.gtmax_host = gtmax; A.gtmax_dev = gmax_dev; A.keep = mask; A.z_out = z;
+    A.kX = KG.X; A.kY = KG.Y; A.kZ = KG.Z; A.pX = PG ? PG->X : 0; A.pY = PG ? PG->Y : 0; A.pZ = PG ? PG->Z : 0; A.ncell2 = (int)((bins / 8 + 1) / 2);
+    A.skey = sorted ? skey : nullptr; A.srank = srank; A.hist = c->ws.hist;
+}
+// halves: 256-cell chunks per workgroup (1: k_sort_scan, 2: the role inside k_decode_bwd_multi)
+static ScanArgs scan_args(nsk_ctx* c, int stage, int* offs, int halves)
+{
+    const size_t bins = c->grid[stage_key_level(stage)].n / 32 * 8;
+    ScanArgs A; A.nkeys = (int)bins; A.ncell2 = (int)((bins / 8 + 1) / 2); A.hist = c->ws.hist; A.offs = offs;
+    A.nblocks = (int)((bins + 2048 * (size_t)halves - 1) / (2048 * (size_t)halves));
+    return A;
+}
+static PlaceArgs place_args(int M, const int* skey, const int* srank, const int* offs, int* perm)
+{
+    PlaceArgs A; A.M = M; A.skey = skey; A.srank = srank; A.offs = offs; A.perm = perm; A.nblocks = (M + 255) / 256;
+    return A;
+}
+// the batch maximum of gt_depth has to come from a launch of its own (k_sample's waves take it themselves for smaller batches)
+static bool needs_depth_max(const float* gt, float gtmax, int N) { return gt && gtmax < 0.f && N > 8192; }
+
+// sampling (+ cell sort) of one batch into the given output set by launches of its own; `done`: stages that have already run (nsk_ctx::Prep)
+static int launch_sampling(nsk_ctx* c, const RParams& R, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax,
+                           const uint8_t* mask, bool sorted, float* z, int* skey, int* srank, int* offs, int* perm, int done = 0)
+{
+    const int M = N * S;
+    hipStream_t st = c->stream;
+    if (!(done & 1)) {
+        const float* gmax_dev = nullptr;
+        if (needs_depth_max(gt, gtmax, N)) {
+            ProfScope ps(c, "depth_max");
+            k_depth_max<<<1, 1024, 0, st>>>(N, gt, mask, c->scal);
+            gmax_dev = c->scal;
+        }
+        ProfScope ps(c, "sample");
+        SampArgs A;
+        samp_args(c, A, R, stage, N, S, ro, rd, gt, gtmax, gmax_dev, mask, sorted, z, skey, srank);
+        k_sample<<<(N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS, 64 * NSK_SAMPLE_RAYS, 0, st>>>(A);
     }
-    {
-    ProfScope ps(c, "sample", prof);
-    k_sample<<<(N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS, 64 * NSK_SAMPLE_RAYS, 0, st>>>(c->R, N, S, ro, rd, gt, gtmax, gmax_dev, mask, z, KG.X, KG.Y, KG.Z, PG ? PG->X : 0, PG ? PG->Y : 0, PG ? PG->Z : 0, (int)((bins / 8 + 1) / 2),
-                                                 sorted ? skey : nullptr, srank, c->ws.hist);
-    }
-    if (sorted) {
-        ProfScope ps(c, "cell_sort", prof);
-        k_sort_scan<<<(int)((bins + 2047) / 2048), 256, 0, st>>>((int)bins, (int)((bins / 8 + 1) / 2), c->ws.hist, offs);
-        k_sort_place<<<(M + 255) / 256, 256, 0, st>>>(M, skey, srank, offs, perm);
+    if (sorted && (done & 6) != 6) {
+        ProfScope ps(c, "cell_sort");
+        if (!(done & 2)) { const ScanArgs A = scan_args(c, stage, offs, 1); k_sort_scan<<<A.nblocks, 256, 0, st>>>(A); }
+        if (!(done & 4)) { const PlaceArgs A = place_args(M, skey, srank, offs, perm); k_sort_place<<<A.nblocks, 256, 0, st>>>(A); }
     }
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-static size_t stage_bins(nsk_ctx* c, int stage)
+// the stages of the prepared batch that have not run yet, by launches of their own (its step has come, or something else needs the histogram)
+static int prep_finish(nsk_ctx* c)
 {
-    int key_level = 0;
-    for (int q = 0; q < 3; ++q) if (STAGE_DEC[stage][q] >= 0) key_level = STAGE_DEC[stage][q];
-    return c->grid[key_level].n / 32 * 8;
+    nsk_ctx::Prep& P = c->prep;
+    if (!P.valid) return 0;
+    const int all = P.sorted ? 7 : 1;
+    if ((P.done & all) == all) return 0;
+    Workspace& w = c->ws;
+    CHK(launch_sampling(c, P.R, P.stage, P.N, P.S, P.ro, P.rd, P.gt, P.gtmax, P.mask, P.sorted, w.z_alt, w.skey_alt, w.srank_alt, w.offs_alt, w.perm_alt, P.done));
+    P.done = all;
+    return 0;
 }
+// forget the prepared batch and any registered one; a histogram that holds its counts is cleared by the scan
+static int prep_drop(nsk_ctx* c)
+{
+    nsk_ctx::Prep& P = c->prep;
+    if (P.valid && P.sorted && (P.done & 1) && !(P.done & 2)) { const ScanArgs A = scan_args(c, P.stage, c->ws.offs_alt, 1); k_sort_scan<<<A.nblocks, 256, 0, c->stream>>>(A); HIPCHK(hipGetLastError()); }
+    P.valid = false; c->req.valid = false;
+    return 0;
+}
+
+static size_t stage_bins(nsk_ctx* c, int stage) { return c->grid[stage_key_level(stage)].n / 32 * 8; }
 
 static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax, bool save_masks,
                         bool sorted = false)
 {
     const int M = N * S;
     const uint8_t* mask = save_masks ? c->ray_mask : nullptr;      // (only the steps that form a loss honour it; a plain render shows every ray)
+    auto is_this_batch = [&](const nsk_ctx::Prep& X) {
+        return X.valid && save_masks && !c->capturing && X.stage == stage && X.N == N && X.S == S && X.ro == ro && X.rd == rd && X.gt == gt && X.gtmax == gtmax &&
+               X.mask == mask && X.sorted == sorted && memcmp(&X.R, &c->R, sizeof(RParams)) == 0;
+    };
     nsk_ctx::Prep& P = c->prep;
-    if (P.valid && save_masks && !c->capturing && P.stage == stage && P.N == N && P.S == S && P.ro == ro && P.rd == rd && P.gt == gt && P.gtmax == gtmax &&
-        P.mask == mask && P.sorted == sorted) {
-        // this batch was sampled by nsk_map_prepare: take its outputs
+    CHK(prep_finish(c));                                    // (also when the set is for another batch: the sampling below needs the cell histogram)
+    if (is_this_batch(P)) {
+        // this batch was sampled during the previous step (nsk_map_prepare): take its outputs
         Workspace& w = c->ws;
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_prep_done, 0));
         std::swap(w.z, w.z_alt); std::swap(w.perm, w.perm_alt); std::swap(w.skey, w.skey_alt); std::swap(w.srank, w.srank_alt);
         std::swap(w.offs, w.offs_alt);                      // (both sets are kept at the same capacities: ensure_alt)
-        P.valid = false; c->prep_outstanding = false;
+        P.valid = false;
         c->sorted = sorted;
     } else {
-        if (c->prep_outstanding) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_prep_done, 0));      // the cell histogram is shared with the side stream
+        if (is_this_batch(c->req)) c->req.valid = false;    // registered, but no step came by to carry its sampling: sampled here like any other batch
         c->sorted = sorted;
         if (sorted) CHK(ensure_hist(c, stage_bins(c, stage)));
-        CHK(launch_sampling(c, c->stream, stage, N, S, ro, rd, gt, gtmax, mask, sorted, c->ws.z, c->ws.skey, c->ws.srank, c->ws.offs, c->ws.perm, c->scal, true));
+        CHK(launch_sampling(c, c->R, stage, N, S, ro, rd, gt, gtmax, mask, sorted, c->ws.z, c->ws.skey, c->ws.srank, c->ws.offs, c->ws.perm));
     }
     CHK(launch_decode_fwd_stage(c, stage, M, S, ro, rd, save_masks));
     return 0;
@@ -1848,13 +1898,23 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
     else split_wgs_balanced(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end, frozen_only ? NSK_FROZEN_NW : 8);
     const int extra = d_loss ? 1 : 0;          // one more workgroup sums the per-ray losses written by k_composite
     if (d_loss) { MA.sum_src = c->ws.ray_loss; MA.sum_dst = d_loss; MA.sum_n = N; }
+    // the prepared batch's cell-sort offsets ride behind the roles (nsk_map_prepare): short workgroups that wait for nothing of this launch
+    int scan_wgs = 0;
+    {
+        nsk_ctx::Prep& P = c->prep;
+        if (P.valid && P.sorted && (P.done & 3) == 1 && !rays && !c->capturing && !c->tune_no_piggyback) {
+            MA.scan = scan_args(c, P.stage, c->ws.offs_alt, frozen_only ? NSK_FROZEN_NW / 4 : 2);
+            scan_wgs = MA.scan.nblocks;
+            P.done |= 2;
+        }
+    }
     {
         ProfScope ps(c, "decode_bwd_multi");
         if (frozen_only) {
             const size_t lds16 = lds - 8 * 3840 + (size_t)NSK_FROZEN_NW * 3840;      // image + one scatter scratch per wave
-            k_decode_bwd_frozen<false><<<MA.wg_end[n - 1] + extra, 64 * NSK_FROZEN_NW, lds16, c->stream>>>(MA);
+            k_decode_bwd_frozen<false><<<MA.wg_end[n - 1] + scan_wgs + extra, 64 * NSK_FROZEN_NW, lds16, c->stream>>>(MA);
         } else if (rays) k_decode_bwd_multi<true><<<MA.wg_end[n - 1] + extra, 512, lds, c->stream>>>(MA);
-        else k_decode_bwd_multi<false><<<MA.wg_end[n - 1] + extra, 512, lds, c->stream>>>(MA);
+        else k_decode_bwd_multi<false><<<MA.wg_end[n - 1] + scan_wgs + extra, 512, lds, c->stream>>>(MA);
     }
     HIPCHK(hipGetLastError());
     if (train_role >= 0) {
@@ -1891,14 +1951,14 @@ static int ensure_alt(nsk_ctx* c, bool need_offs)
 {
     Workspace& w = c->ws;
     if (w.alt_capM < w.capM) {
-        HIPCHK(hipStreamSynchronize(c->stream2));
+        HIPCHK(hipStreamSynchronize(c->stream));
         hipFree(w.z_alt); hipFree(w.perm_alt); hipFree(w.skey_alt); hipFree(w.srank_alt);
         const size_t m = (size_t)w.capM + 64;
         HIPCHK(hipMalloc(&w.z_alt, m * 4)); HIPCHK(hipMalloc(&w.perm_alt, m * 4)); HIPCHK(hipMalloc(&w.skey_alt, m * 4)); HIPCHK(hipMalloc(&w.srank_alt, m * 4));
         w.alt_capM = w.capM;
     }
     if (need_offs && w.alt_bins < w.hist_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream2));
+        HIPCHK(hipStreamSynchronize(c->stream));
         hipFree(w.offs_alt);
         HIPCHK(hipMalloc(&w.offs_alt, w.hist_cap * 4));
         w.alt_bins = w.hist_cap;
@@ -1906,32 +1966,37 @@ static int ensure_alt(nsk_ctx* c, bool need_offs)
     return 0;
 }
 
+// Registers the NEXT batch.  Nothing is launched here: the nsk_map_step that follows carries the batch's sampling in its composite launch, its
+// backward launch carries the offsets of the cell sort, the nsk_adam_step after it the placement -- three launches and their dependent round
+// trips (30 us at 5000 rays, 20 us at 1000) leave the front of the next step.  Until round 3 the sampling ran on a side stream beside the
+// exchange and the optimiser step: that needed two cross-stream waits per step and lost on one GPU (K3 0.511 against 0.500 ms).
+// Whatever has not been carried when the batch's own step arrives is launched there, as for an unprepared batch.
 extern "C" int nsk_map_prepare(nsk_ctx* c, int stage, int N, const float* ro, const float* rd, const float* gt, float gtmax, unsigned flags)
 {
     int S;
     if (!gt) return fail("nsk_map_prepare: gt_depth is NULL");
     if (c && c->capturing) return fail("nsk_map_prepare: not inside a graph capture");
     CHK(common_checks(c, stage, N, ro, rd, &S, gt));
-    if (!c->stream2) {
-        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_prep_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_alt_free, hipEventDisableTiming));
-    }
     const bool sorted = sort_pays(c, stage, N * S, flags);
     if (sorted) CHK(ensure_hist(c, stage_bins(c, stage)));
     CHK(ensure_alt(c, sorted));
-    // The side stream starts when everything enqueued on the main stream SO FAR has finished -- the step just issued, i.e. it runs beside
-    // whatever the caller enqueues next (the gradient exchange, the optimiser step).  Sampling beside the step's own decoder launches
-    // was measured and lost: the GPU is full, the forward slowed by what the sampling took and the cross-stream waits came on top
-    // (K3 0.511 against 0.500 ms, K2 0.163 against 0.151 ms).  This one wait also covers both hazards: the set being overwritten
-    // (last read by earlier steps) and the cell histogram (shared with the main stream's own sampling).
-    HIPCHK(hipEventRecord(c->ev_alt_free, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_alt_free, 0));
-    Workspace& w = c->ws;
-    CHK(launch_sampling(c, c->stream2, stage, N, S, ro, rd, gt, gtmax, c->ray_mask, sorted, w.z_alt, w.skey_alt, w.srank_alt, w.offs_alt, w.perm_alt, c->scal + 12, false));
-    HIPCHK(hipEventRecord(c->ev_prep_done, c->stream2));
-    c->prep_outstanding = true;
-    nsk_ctx::Prep& P = c->prep;
-    P.valid = true; P.stage = stage; P.N = N; P.S = S; P.ro = ro; P.rd = rd; P.gt = gt; P.gtmax = gtmax; P.mask = c->ray_mask; P.sorted = sorted;
+    nsk_ctx::Prep& P = c->req;
+    P.valid = true; P.stage = stage; P.N = N; P.S = S; P.ro = ro; P.rd = rd; P.gt = gt; P.gtmax = gtmax; P.mask = c->ray_mask; P.sorted = sorted; P.done = 0; P.R = c->R;
+    return 0;
+}
+
+// a registered batch becomes the prepared one (the second set is free: the step that was using it has swapped it out); ride: its sampling may
+// go into this step's composite launch
+static int prep_promote(nsk_ctx* c, bool* ride)
+{
+    *ride = false;
+    if (!c->req.valid || c->capturing) return 0;
+    if (c->prep.valid) { const nsk_ctx::Prep keep = c->req; CHK(prep_drop(c)); c->req = keep; }      // an unclaimed set makes room
+    const nsk_ctx::Prep R = c->req;
+    if (R.sorted) CHK(ensure_hist(c, stage_bins(c, R.stage)));
+    CHK(ensure_alt(c, R.sorted));
+    c->prep = R; c->prep.done = 0; c->req.valid = false;
+    *ride = !c->tune_no_piggyback && !needs_depth_max(R.gt, R.gtmax, R.N);
     return 0;
 }
 
@@ -1950,7 +2015,18 @@ extern "C" int nsk_map_step(nsk_ctx* c, int stage, int N, const float* ro, const
     A.mode = 2; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
     A.rgb = rgb; A.depth = depth; A.var = var; A.loss = c->ws.ray_loss;
     if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
-    { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
+    bool ride = false;
+    CHK(prep_promote(c, &ride));
+    if (ride) {          // the next batch's sampling behind this batch's compositing, one launch (k_composite_sample)
+        nsk_ctx::Prep& P = c->prep;
+        SampArgs SA;
+        samp_args(c, SA, P.R, P.stage, P.N, P.S, P.ro, P.rd, P.gt, P.gtmax, nullptr, P.mask, P.sorted, c->ws.z_alt, c->ws.skey_alt, c->ws.srank_alt);
+        const int cb = (N + 7) / 8, sb = (P.N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS;
+        { ProfScope ps(c, "composite"); k_composite_sample<<<cb + sb, 512, 0, c->stream>>>(A, SA, cb); }
+        P.done |= 1;
+    } else {
+        ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
+    }
     HIPCHK(hipGetLastError());
     CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd, d_loss));
     account(c, stage, N * S, N, true, flags);
@@ -2330,7 +2406,16 @@ extern "C" int nsk_adam_step(nsk_ctx* c, const float lr[NSK_NUM_GROUPS], float b
         for (int i = 0; i < AA.n; ++i) { ca.group[i] = seg_group[i]; ca.lr[i] = lr[seg_group[i]]; }
         c->cap_adams.push_back(ca);
     }
-    if (AA.n) { ProfScope ps(c, "adam_multi"); k_adam_multi<<<blocks, 256, 0, c->stream>>>(AA); }
+    int place_wgs = 0;
+    {   // the prepared batch's cell-sort placement rides behind the segments (nsk_map_prepare)
+        nsk_ctx::Prep& P = c->prep;
+        if (AA.n && P.valid && P.sorted && (P.done & 7) == 3 && !c->capturing && !c->tune_no_piggyback) {
+            AA.place = place_args(P.N * P.S, c->ws.skey_alt, c->ws.srank_alt, c->ws.offs_alt, c->ws.perm_alt);
+            AA.adam_blocks = blocks; place_wgs = AA.place.nblocks;
+            P.done |= 4;
+        }
+    }
+    if (AA.n) { ProfScope ps(c, "adam_multi"); k_adam_multi<<<blocks + place_wgs, 256, 0, c->stream>>>(AA); }
     if (PA.n) { ProfScope ps(c, "pack_images"); k_pack_multi<<<pblocks, 256, 0, c->stream>>>(PA); }
     HIPCHK(hipGetLastError());
     return 0;

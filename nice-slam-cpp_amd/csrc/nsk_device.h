@@ -160,17 +160,24 @@ __device__ __forceinline__ int cell_index(int GX, int GY, int GZ, const float* b
 #define NSK_SAMPLE_RAYS 8           // rays (waves) per workgroup of k_sample (16: 19.6 us at 5000 rays, 8: 18.1, 4: 20.9; 1000 rays: 11.5 / 10.6 / 12.3)
 #endif
 #define NSK_SAMPLE_TABLE 2048       // slots of its cell table (>= 2 x NSK_SAMPLE_RAYS x 64 keeps probing short)
-__global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int N, int S, const float* __restrict__ rays_o,
-                                                const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
-                                                float gtmax_host, const float* __restrict__ gtmax_dev, const uint8_t* __restrict__ keep,
-                                                float* __restrict__ z_out, int kX, int kY, int kZ, int pX, int pY, int pZ, int ncell2,
-                                                int* __restrict__ skey, int* __restrict__ srank, int* __restrict__ hist)
+struct SampArgs {
+    RParams R; int N, S;
+    const float* rays_o; const float* rays_d; const float* gt_depth; float gtmax_host; const float* gtmax_dev; const uint8_t* keep;
+    float* z_out; int kX, kY, kZ, pX, pY, pZ, ncell2; int* skey; int* srank; int* hist;
+};
+// (a body, so that the sampling of the NEXT batch can ride in the composite launch of the current step: k_composite_sample, nsk_map_prepare)
+__device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
 {
+    const RParams& R = P.R;
+    const int N = P.N, S = P.S, kX = P.kX, kY = P.kY, kZ = P.kZ, pX = P.pX, pY = P.pY, pZ = P.pZ, ncell2 = P.ncell2;
+    const float* __restrict__ rays_o = P.rays_o; const float* __restrict__ rays_d = P.rays_d; const float* __restrict__ gt_depth = P.gt_depth;
+    const float gtmax_host = P.gtmax_host; const float* __restrict__ gtmax_dev = P.gtmax_dev; const uint8_t* __restrict__ keep = P.keep;
+    float* __restrict__ z_out = P.z_out; int* __restrict__ skey = P.skey; int* __restrict__ srank = P.srank; int* __restrict__ hist = P.hist;
     __shared__ float sh[NSK_SAMPLE_RAYS][64];
     __shared__ float sh2[NSK_SAMPLE_RAYS][64];
     __shared__ int tkey[NSK_SAMPLE_TABLE], tcnt[NSK_SAMPLE_TABLE], tbase[NSK_SAMPLE_TABLE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * NSK_SAMPLE_RAYS + wave;
+    const int n = bid * NSK_SAMPLE_RAYS + wave;
     const bool active = n < N;                          // whole waves; inactive ones only take part in the barriers below
     const int nc = active ? n : N - 1;
     const bool has_gt = gt_depth != nullptr;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int 
     if (active && lane < S) z_out[(size_t)n * S + lane] = z;
     if (!skey) return;                                                      // uniform over the launch
     // ---- cell keys and ranks for the cell sort -----------------------------------------------------------------------------
-    if (blockIdx.x == 0 && threadIdx.x == 0) hist[-1] = 0;                 // the bump cursor of k_sort_scan (one int in front of the histogram)
+    if (bid == 0 && threadIdx.x == 0) hist[-1] = 0;                 // the bump cursor of k_sort_scan (one int in front of the histogram)
     for (int i = threadIdx.x; i < NSK_SAMPLE_TABLE; i += 64 * NSK_SAMPLE_RAYS) { tkey[i] = -1; tcnt[i] = 0; }
     int cell = -1;
     if (active && lane < S) {
@@ -291,15 +298,22 @@ __global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(RParams R, int 
     base = __shfl(base, start);
     if (active && lane < S) { skey[(size_t)n * S + lane] = cell; srank[(size_t)n * S + lane] = base + (lane - start); }
 }
+__global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(SampArgs P) { sample_body(P, blockIdx.x); }
 
 // Offsets of the cell sort.  Each workgroup scans a chunk of 256 consecutive cells (2048 keys; one cell = 8 keys per thread) and
 // takes the chunk's place in the output with ONE returning add on a cursor: chunks land in arrival order (keys stay sorted
 // inside a chunk, which is all the tiles need), and no workgroup waits for another.  The histogram is cleared for the next step.
-__global__ __launch_bounds__(256) void k_sort_scan(int nkeys, int ncell2, int* __restrict__ hist, int* __restrict__ offs)
+// (a body over 256 threads = one chunk; HALVES chunks per workgroup, so that the scan can ride in a 512-thread launch: k_decode_bwd_multi)
+struct ScanArgs { int nkeys, ncell2; int* hist; int* offs; int nblocks; };
+template <int HALVES>
+__device__ __forceinline__ void sort_scan_body(const ScanArgs& P, int bid)
 {
-    __shared__ int wsum[4];
-    __shared__ int sbase;
-    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    __shared__ int wsum_[HALVES][4];
+    __shared__ int sbase_[HALVES];
+    const int half = HALVES > 1 ? (int)(threadIdx.x >> 8) : 0, tid = threadIdx.x & 255;
+    int* wsum = wsum_[half]; int& sbase = sbase_[half];
+    const int nkeys = P.nkeys, ncell2 = P.ncell2; int* __restrict__ hist = P.hist; int* __restrict__ offs = P.offs;
+    const int c0 = ((bid * HALVES + half) * 256 + tid) * 8;
     int v[8], s = 0;
     if (c0 < nkeys) {
         const int4* src = reinterpret_cast<const int4*>(hist + hist_slot(c0, ncell2));
@@ -312,12 +326,12 @@ __global__ __launch_bounds__(256) void k_sort_scan(int nkeys, int ncell2, int* _
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += v[i];
     int incl = s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) sbase = atomicAdd(hist - 1, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (tid == 0) sbase = atomicAdd(hist - 1, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
     __syncthreads();
     int run = sbase + incl - s;
     for (int w = 0; w < wave; ++w) run += wsum[w];
@@ -330,13 +344,15 @@ __global__ __launch_bounds__(256) void k_sort_scan(int nkeys, int ncell2, int* _
         if (s) { int4* h = reinterpret_cast<int4*>(hist + hist_slot(c0, ncell2)); h[0] = make_int4(0, 0, 0, 0); h[1] = make_int4(0, 0, 0, 0); }
     }
 }
+__global__ __launch_bounds__(256) void k_sort_scan(ScanArgs P) { sort_scan_body<1>(P, blockIdx.x); }
 
-__global__ void k_sort_place(int M, const int* __restrict__ skey, const int* __restrict__ srank, const int* __restrict__ offs,
-                             int* __restrict__ perm)
+struct PlaceArgs { int M; const int* skey; const int* srank; const int* offs; int* perm; int nblocks; };
+__device__ __forceinline__ void sort_place_body(const PlaceArgs& P, int bid)
 {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < M) perm[offs[skey[m]] + srank[m]] = m;
+    const int m = bid * blockDim.x + threadIdx.x;
+    if (m < P.M) P.perm[P.offs[P.skey[m]] + P.srank[m]] = m;
 }
+__global__ void k_sort_place(PlaceArgs P) { sort_place_body(P, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------------
 // trilinear lookup = F::grid_sample(bilinear, border, align_corners=true) (reference src/models/MLP.cpp:51-63,
@@ -916,6 +932,7 @@ __global__ __launch_bounds__(512) void k_decode_fwd(DecArgs A) { decode_fwd_body
 struct MultiArgs {
     DecArgs a[3]; int which[3]; int train[3]; int wg_end[3]; int n;
     const float* sum_src; float* sum_dst; int sum_n;      // optional: one extra workgroup sums the per-ray losses (saves a launch)
+    ScanArgs scan;                                        // optional (scan.nblocks > 0): the NEXT batch's cell-sort offsets ride behind the roles (nsk_map_prepare)
 };
 
 __device__ __forceinline__ void block_sum(const float* __restrict__ x, int n, float* __restrict__ out)
@@ -989,10 +1006,11 @@ __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f
 // is resident: the host uses this mode only while the grid has at most one workgroup per CU), each workgroup then finds
 // 10 x the lower median by rank counting.  One launch instead of composite + k_median_thr + composite (Tracker.cpp:67-71).
 #define NSK_MEDIAN_FUSED_MAX 1024         // rays (LDS copy of the residuals; the host also caps the grid at one workgroup per CU)
-__global__ __launch_bounds__(256) void k_composite(CompArgs A)
+template <int RPW>           // rays (waves) per workgroup; bid / nb: this role's workgroup index and count inside the launch
+__device__ __forceinline__ void composite_body(const CompArgs& A, int bid, int nb)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int n = blockIdx.x * 4 + wave;
+    int n = bid * RPW + wave;
     if (n >= A.N) {
         if (A.mode != 4) return;
         n = A.N - 1;                       // mode 4 has workgroup barriers: a spare wave of the last workgroup repeats the last ray (same stores)
@@ -1059,21 +1077,21 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
             // with the threshold at infinity and the flag bar[2] set, which nsk_sync reports)
             __hip_atomic_fetch_add(&A.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int spins = 0;
-            while (__hip_atomic_load(&A.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            while (__hip_atomic_load(&A.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nb) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1 << 20)) { A.bar[2] = 1u; break; }
             }
         }
         __syncthreads();
         const int N4 = (A.N + 3) & ~3;
-        for (int i = threadIdx.x; i < N4; i += 256) {
+        for (int i = threadIdx.x; i < N4; i += 64 * RPW) {
             const float v = i < A.N ? __hip_atomic_load(&A.resid[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NSK_INF;
             rs[i] = v;
             if (v < NSK_INF) atomicAdd(&s_valid, 1);
         }
         __syncthreads();
         const int target = (max(s_valid, 1) - 1) / 2;          // torch.median: the lower median of the valid residuals
-        for (int i = threadIdx.x; i < A.N; i += 256) {         // rank of residual i in the order (value, index); four comparisons per LDS read
+        for (int i = threadIdx.x; i < A.N; i += 64 * RPW) {         // rank of residual i in the order (value, index); four comparisons per LDS read
             const float v = rs[i];
             int rank = 0;
             for (int k = 0; k < N4; k += 4) {
@@ -1086,9 +1104,9 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
         __syncthreads();
         thr_here = s_thr;
         if (threadIdx.x == 0) {
-            if (blockIdx.x == 0 && A.thr_out) *A.thr_out = thr_here;
+            if (bid == 0 && A.thr_out) *A.thr_out = thr_here;
             const unsigned old = __hip_atomic_fetch_add(&A.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == gridDim.x - 1) {         // the last workgroup to leave re-arms the barrier for the next launch
+            if (old == (unsigned)nb - 1) {         // the last workgroup to leave re-arms the barrier for the next launch
                 __hip_atomic_store(&A.bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&A.bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1164,6 +1182,15 @@ __global__ __launch_bounds__(256) void k_composite(CompArgs A)
             A.g_rays_o[3 * n + lane] = 0.f;
         }
     }
+}
+__global__ __launch_bounds__(256) void k_composite(CompArgs A) { composite_body<4>(A, blockIdx.x, gridDim.x); }
+// The Mapper's compositing with the NEXT batch's sampling behind it in the same launch (nsk_map_prepare): the sampling's chain of dependent
+// round trips runs beside the compositing's instead of in front of the next step's forward.  Eight rays per workgroup for both roles.
+static_assert(NSK_SAMPLE_RAYS == 8, "k_composite_sample: both roles use 512-thread workgroups");
+__global__ __launch_bounds__(512) void k_composite_sample(CompArgs A, SampArgs P, int comp_blocks)
+{
+    if ((int)blockIdx.x < comp_blocks) composite_body<8>(A, blockIdx.x, comp_blocks);
+    else sample_body(P, (int)blockIdx.x - comp_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1496,6 +1523,7 @@ template <bool RAYS>
 __global__ __launch_bounds__(64 * NSK_FROZEN_NW) void k_decode_bwd_frozen(MultiArgs MA)
 {
     if (MA.sum_n > 0 && blockIdx.x == gridDim.x - 1) { block_sum(MA.sum_src, MA.sum_n, MA.sum_dst); return; }
+    if ((int)blockIdx.x >= MA.wg_end[MA.n - 1]) { sort_scan_body<NSK_FROZEN_NW / 4>(MA.scan, (int)blockIdx.x - MA.wg_end[MA.n - 1]); return; }      // see k_decode_bwd_multi
     int r = 0;
     while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
     const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];

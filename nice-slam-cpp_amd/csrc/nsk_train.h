@@ -1281,6 +1281,11 @@ template <bool RAYS>
 __global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
 {
     if (MA.sum_n > 0 && blockIdx.x == gridDim.x - 1) { block_sum(MA.sum_src, MA.sum_n, MA.sum_dst); return; }
+    if constexpr (!RAYS) {
+        // the NEXT batch's cell-sort offsets (nsk_map_prepare): short workgroups behind the roles', two 256-cell chunks each; they start when the last
+        // frozen workgroup has been placed and need nothing of this launch
+        if ((int)blockIdx.x >= MA.wg_end[MA.n - 1]) { sort_scan_body<2>(MA.scan, (int)blockIdx.x - MA.wg_end[MA.n - 1]); return; }
+    }
     NSK_TS_BEGIN(1);
     int r = 0;
     while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;

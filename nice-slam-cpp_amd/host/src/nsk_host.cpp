@@ -641,7 +641,7 @@ void Tracker::run(SequenceReader& reader, NICE decoders)
 struct Mapper::Dev {
     DevFrame cur;                                        // current frame
     std::vector<std::shared_ptr<DevFrame>> kf;           // keyframes, index = position in keyframe_vector
-    RayBufs rays;
+    RayBufs rays, rays2;             // two sets: the next iteration's batch is drawn and registered (nsk_map_prepare) while this one's is optimised
     DevArr<float> poses;                                 // [frames of the window][12] fixed c2w rows (3x4)
     DevArr<float> cams, cam_m, cam_v, cam_g;             // BA: [frames][8] pose 7-vectors, their Adam moments and their last gradients
     DevArr<float> loss;
@@ -801,19 +801,39 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     D.poses.upload(h_pose.data(), h_pose.size());
     D.cams.upload(h_cam.data(), h_cam.size());
     D.cam_m.zero((size_t)nf * 8); D.cam_v.zero((size_t)nf * 8); D.cam_g.zero((size_t)nf * 8);
-    D.rays.ensure((size_t)N); D.loss.ensure((size_t)std::max(4, num_joint_iters_));           // one loss slot per iteration
-    RayBufs& R = D.rays;
+    D.rays.ensure((size_t)N); D.rays2.ensure((size_t)N); D.loss.ensure((size_t)std::max(4, num_joint_iters_));           // one loss slot per iteration
+    RayBufs* bufs[2] = {&D.rays, &D.rays2};
     const bool any_ba = BA && std::count(is_ba.begin(), is_ba.end(), 1) > 0;
     int ba_step = 0;
     const uint64_t call_seed = draw_seed(rng_seed, ++draw_calls);                             // a new pixel stream every call (the reference draws
                                                                                               // fresh torch::randint pixels, utils.h:19-36, Mapper.cpp:376-414)
     check(nsk_sync(ctx()));
     const double t0 = now_us();
+    auto stage_of = [&](int it) -> std::string {                                              // :351-358 (D18 intended)
+        if (coarse_mapper) return "coarse";
+        if (it <= int(num_joint_iters_ * middle_iter_ratio)) return "middle";
+        if (it <= int(num_joint_iters_ * fine_iter_ratio)) return "fine";
+        return "color";
+    };
+    // src/Mapper.cpp:430 renders the literal "color" whatever the stage (D19); the colour term of the loss follows `stage` (:438)
+    auto render_stage_of = [&](int it) { return (render_stage_literal_color && !coarse_mapper) ? std::string("color") : stage_of(it); };
+    // rays of every window frame (:376-414) for iteration `it`: pixel draw, ground-truth gather and ray generation on the device
+    // (one launch for the window: it was 3 per frame + the filter = 16 launches of a 118 us iteration with five frames)
+    auto draw_rays = [&](int it, RayBufs& R) {
+        frame_tab.resize(nf);
+        for (int i = 0; i < nf; ++i) {
+            const int f = optimize_frame[i];
+            const DevFrame& F = f >= 0 ? *D.kf[f] : D.cur;
+            frame_tab[i] = nsk_frame_rays{F.depth.p, F.color.p, is_ba[i] ? D.cams.p + 8 * i : D.poses.p + 12 * i, is_ba[i] ? 1 : 0,
+                                          call_seed + 0x100000001b3ull * (uint64_t)(it * nf + i + 1)};
+        }
+        check(nsk_prepare_rays(ctx(), nf, frame_tab.data(), pixs_per_image, 0, H, 0, W, D.cur.H, D.cur.W, fx, fy, cx, cy, 0, R.pi.p, R.pj.p, R.gd.p, R.gc.p,
+                               R.ro.p, R.rd.p, R.keep.p));                                    // :416-427 included: rays that leave the bound before their depth
+    };                                                                                        // ... are neutralised in place (no count on the host)
+    int drawn_upto = -1;                                                                      // last iteration whose rays have been drawn
     for (int joint_iter = 0; joint_iter < num_joint_iters_; ++joint_iter) {
-        if (coarse_mapper) stage = "coarse";                                                  // :351-358 (D18 intended)
-        else if (joint_iter <= int(num_joint_iters_ * middle_iter_ratio)) stage = "middle";
-        else if (joint_iter <= int(num_joint_iters_ * fine_iter_ratio)) stage = "fine";
-        else stage = "color";
+        stage = stage_of(joint_iter);
+        RayBufs& R = *bufs[joint_iter & 1];
         float lr[NSK_NUM_GROUPS];
         auto st = ns_cfg["mapping"]["stage"][stage];
         lr[NSK_GROUP_DECODERS] = st["decoders_lr"].as<float>() * lr_factor;                   // :360-364
@@ -823,21 +843,18 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
         lr[NSK_GROUP_COLOR] = st["color_lr"].as<float>() * lr_factor;
         lr[NSK_GROUP_CAMERA] = 0.f;
         const bool ba_now = any_ba && stage == "color";                                       // :366-368
-        // rays of every window frame (:376-414): pixel draw, ground-truth gather and ray generation on the device
-        // (one launch for the window: it was 3 per frame + the filter = 16 launches of a 118 us iteration with five frames)
-        frame_tab.resize(nf);
-        for (int i = 0; i < nf; ++i) {
-            const int f = optimize_frame[i];
-            const DevFrame& F = f >= 0 ? *D.kf[f] : D.cur;
-            frame_tab[i] = nsk_frame_rays{F.depth.p, F.color.p, is_ba[i] ? D.cams.p + 8 * i : D.poses.p + 12 * i, is_ba[i] ? 1 : 0,
-                                          call_seed + 0x100000001b3ull * (uint64_t)(joint_iter * nf + i + 1)};
+        if (drawn_upto < joint_iter) { draw_rays(joint_iter, R); drawn_upto = joint_iter; }
+        // The next iteration's batch is drawn and registered before this one is optimised, so that its sampling and cell sort ride in this
+        // iteration's launches (nsk_map_prepare) -- unless its rays depend on this iteration's result (bundle adjustment moves the poses)
+        if (joint_iter + 1 < num_joint_iters_ && !(any_ba && stage_of(joint_iter + 1) == "color")) {
+            RayBufs& Rn = *bufs[(joint_iter + 1) & 1];
+            draw_rays(joint_iter + 1, Rn); drawn_upto = joint_iter + 1;
+            check(nsk_set_ray_mask(ctx(), Rn.keep.p));
+            check(nsk_map_prepare(ctx(), nskh::stage_id(render_stage_of(joint_iter + 1)), N, Rn.ro.p, Rn.rd.p, Rn.gd.p, -1.f, NSK_GRAD_GRIDS | NSK_GRAD_DECODERS));
         }
-        check(nsk_prepare_rays(ctx(), nf, frame_tab.data(), pixs_per_image, 0, H, 0, W, D.cur.H, D.cur.W, fx, fy, cx, cy, 0, R.pi.p, R.pj.p, R.gd.p, R.gc.p,
-                               R.ro.p, R.rd.p, R.keep.p));                                    // :416-427 included: rays that leave the bound before their depth
-        check(nsk_set_ray_mask(ctx(), R.keep.p));                                             // ... are neutralised in place (no count on the host)
+        check(nsk_set_ray_mask(ctx(), R.keep.p));
         unsigned flags = NSK_GRAD_GRIDS | NSK_GRAD_DECODERS | (ba_now ? NSK_GRAD_RAYS : 0u);
-        // src/Mapper.cpp:430 renders the literal "color" whatever the stage (D19); the colour term of the loss follows `stage` (:438)
-        const std::string render_stage = (render_stage_literal_color && !coarse_mapper) ? std::string("color") : stage;
+        const std::string render_stage = render_stage_of(joint_iter);
         check(nsk_map_step(ctx(), nskh::stage_id(render_stage), N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, stage == "color" ? 1 : 0, flags,
                            D.loss.p + joint_iter, nullptr, nullptr, nullptr, ba_now ? R.g_ro.p : nullptr, ba_now ? R.g_rd.p : nullptr));      // :430-444
         check(nsk_set_ray_mask(ctx(), nullptr));

@@ -344,7 +344,8 @@ class Context:
 
     @_ordered
     def map_prepare(self, stage, rays_o, rays_d, gt_depth, gt_depth_max=-1.0, flags=GRAD_GRIDS | GRAD_DECODERS):
-        """nsk_map_prepare: sample (and cell-sort) the NEXT batch on the context's side stream while the current step runs"""
+        """nsk_map_prepare: register the NEXT batch before the current batch's map_step; its sampling and cell sort then ride in that step's
+        composite / backward / Adam launches (include/nsk.h)"""
         _chk(lib().nsk_map_prepare(self.h, _stage(stage), rays_o.shape[0], _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), C.c_float(gt_depth_max), C.c_uint(flags)))
 
     @_ordered

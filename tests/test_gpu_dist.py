@@ -188,37 +188,58 @@ def test_deterministic_debug_mode_is_bit_reproducible():
     assert out["det_a"][2] == out["det_b"][2]
 
 
-def test_map_prepare_gives_the_unprepared_steps():
-    """nsk_map_prepare (sampling + cell sort of the next batch on the side stream): four mapping steps over two alternating batches with
-    every next batch prepared, against the same steps without it -- same losses and parameters up to the order of the gradient sums,
-    and the prepared steps really skip their own sampling launches"""
+@pytest.mark.parametrize("case", ["color-sorted", "color-unsorted", "fine-sorted", "color-late", "color-interrupted", "color-off"])
+def test_map_prepare_gives_the_unprepared_steps(case):
+    """nsk_map_prepare (the next batch's sampling rides in this step's composite launch, the cell sort's offsets in the backward launch, its
+    placement in the Adam launch): five mapping steps over two alternating batches with every next batch registered before the step, against
+    the same steps without it -- same losses and parameters up to the order of the gradient sums -- and the prepared steps really have no
+    sampling launches of their own.  Cases: cell-sorted and ray-order steps; the fine stage (no trainable decoder: the offsets ride in
+    k_decode_bwd_frozen); "late" = registered AFTER the step (nothing left to ride in: sampled at the start of its own step, as before);
+    "interrupted" = another batch is rendered between the step and the optimiser (the histogram is needed: the remaining stages are
+    launched at once); "off" = nsk_set_tuning("no_piggyback", 1)."""
+    stage = "fine" if case.startswith("fine") else "color"
     sc = scenes.make_scene(11, grid_std=0.05)
     batches = []
     for k in range(2):
         r = scenes.make_rays(50 + k, 400, sc["bound"], n_frames=5)
         batches.append([cu(r[x]) for x in ("rays_o", "rays_d", "gt_depth", "gt_color")] + [float(r["gt_depth"].max())])
+    other = scenes.make_rays(77, 96, sc["bound"], n_frames=2)
+    oro, ord_, ogd = cu(other["rays_o"]), cu(other["rays_d"]), cu(other["gt_depth"])
     out = []
     for prepare in (False, True):
-        ctx = make_ctx(sc, trainable=["color"])
-        ctx.set_sort_mode(1)
+        ctx = make_ctx(sc, trainable=["color"] if stage == "color" else [])
+        ctx.set_sort_mode(0 if case.endswith("unsorted") else 1)
+        if case.endswith("off"):
+            ctx.set_tuning("no_piggyback", 1)
         loss = torch.zeros(1, device="cuda")
         losses, names = [], None
+        flags = 3 if stage == "color" else 1
         with torch.cuda.stream(ctx.tstream):
-            for i in range(4):
+            for i in range(5):
                 ro, rd, gd, gc, gm = batches[i % 2]
+                n = batches[(i + 1) % 2]
                 if i == 2:
                     ctx.profile_begin()
-                ctx.map_step("color", ro, rd, gd, gc, gm, 0.2, True, flags=3, loss=loss)
-                if prepare:
-                    n = batches[(i + 1) % 2]
-                    ctx.map_prepare("color", n[0], n[1], n[2], n[4], flags=3)
+                if prepare and not case.endswith("late"):
+                    ctx.map_prepare(stage, n[0], n[1], n[2], n[4], flags=flags)
+                ctx.map_step(stage, ro, rd, gd, gc, gm, 0.2, stage == "color", flags=flags, loss=loss)
+                if prepare and case.endswith("late"):
+                    ctx.map_prepare(stage, n[0], n[1], n[2], n[4], flags=flags)
+                if case.endswith("interrupted"):
+                    ctx.render_forward(stage, oro, ord_, ogd, float(other["gt_depth"].max()))
                 ctx.adam_step(LR)
                 losses.append(float(loss))
             names = set(ctx.profile_end().keys())
         out.append((losses, {k: ctx.grid_download(k) for k in ("middle", "fine", "color")}, ctx.decoder_download("color"), names))
         ctx.close()
     (l0, g0, d0, n0), (l1, g1, d1, n1) = out
-    assert "sample" in n0 and "cell_sort" in n0 and "sample" not in n1 and "cell_sort" not in n1
+    assert "sample" in n0
+    if case in ("color-sorted", "color-unsorted", "fine-sorted"):
+        assert "sample" not in n1 and "cell_sort" not in n1, n1          # everything rode along
+    elif case == "color-interrupted":
+        assert "cell_sort" in n1                                          # (the render's own sampling is in there as well)
+    else:
+        assert "sample" in n1
     assert np.allclose(l0, l1, rtol=1e-5)
     for k in g0:
         assert rel_l2(g1[k] - sc["grids"][k], g0[k] - sc["grids"][k]) < 5e-3, k          # (Adam amplifies last-bit differences of the sums: see test_gpu_configs)

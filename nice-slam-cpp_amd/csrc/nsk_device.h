@@ -176,6 +176,7 @@ __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
     __shared__ float sh[NSK_SAMPLE_RAYS][64];
     __shared__ float sh2[NSK_SAMPLE_RAYS][64];
     __shared__ int tkey[NSK_SAMPLE_TABLE], tcnt[NSK_SAMPLE_TABLE], tbase[NSK_SAMPLE_TABLE];
+    __shared__ int tlist[64 * NSK_SAMPLE_RAYS], nlist;      // the occupied slots of the table, in order of arrival
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = bid * NSK_SAMPLE_RAYS + wave;
     const bool active = n < N;                          // whole waves; inactive ones only take part in the barriers below
@@ -253,6 +254,7 @@ __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
     // ---- cell keys and ranks for the cell sort -----------------------------------------------------------------------------
     if (bid == 0 && threadIdx.x == 0) hist[-1] = 0;                 // the bump cursor of k_sort_scan (one int in front of the histogram)
     for (int i = threadIdx.x; i < NSK_SAMPLE_TABLE; i += 64 * NSK_SAMPLE_RAYS) { tkey[i] = -1; tcnt[i] = 0; }
+    if (threadIdx.x == 0) nlist = 0;
     int cell = -1;
     if (active && lane < S) {
         const float px = add_rn(ox, mul_rn(dx, z)), py = add_rn(oy, mul_rn(dy, z)), pz = add_rn(oz, mul_rn(dz, z));   // = sample_finish
@@ -284,15 +286,17 @@ __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
         unsigned h = ((unsigned)cell * 2654435761u) >> 21;                        // 11 bits
         for (;;) {
             const int old = atomicCAS(&tkey[h], -1, cell);
-            if (old == -1 || old == cell) break;
+            if (old == -1) { tlist[atomicAdd(&nlist, 1)] = (int)h; break; }       // first run of this cell in the workgroup
+            if (old == cell) break;
             h = (h + 1) & (NSK_SAMPLE_TABLE - 1);
         }
         slot = (int)h;
         off = atomicAdd(&tcnt[h], next - lane);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NSK_SAMPLE_TABLE; i += 64 * NSK_SAMPLE_RAYS)
-        if (tkey[i] >= 0) tbase[i] = atomicAdd(hist + hist_slot(tkey[i], ncell2), tcnt[i]);
+    // one returning add per distinct cell, ONE per thread (at most 64 x rays distinct cells): walking the table itself, a thread met up to
+    // four occupied slots and made their adds one after the other -- two to three round trips of the 18 us this launch took at 5000 rays
+    if ((int)threadIdx.x < nlist) { const int i = tlist[threadIdx.x]; tbase[i] = atomicAdd(hist + hist_slot(tkey[i], ncell2), tcnt[i]); }
     __syncthreads();
     int base = leader ? tbase[slot] + off : 0;
     base = __shfl(base, start);

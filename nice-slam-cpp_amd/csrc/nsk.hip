@@ -2056,6 +2056,8 @@ extern "C" int nsk_track_step(nsk_ctx* c, int stage, int N, const float* ro, con
     comp_args(c, A, stage, N, S, ro, rd);
     // One launch (k_composite mode 4: residuals -> grid barrier -> median -> loss and backward) while the grid is at most one
     // workgroup per CU, i.e. certainly resident as a whole; three launches otherwise (and in the deterministic debug mode)
+    // (round 3 tried ONE 16-wave workgroup for up to 256 rays -- render, select the median in LDS, render again, no grid barrier: 70 us at 200 rays
+    // against 21, a wave's rays run one after the other at ~2.5 us each)
     const bool fused_median = handle_dynamic && !c->deterministic && !c->tune_no_fused_median && N <= NSK_MEDIAN_FUSED_MAX && (N + 3) / 4 <= c->num_cu;
     if (handle_dynamic && !fused_median) {                     // forward pass for the median (Tracker.cpp:69-70)
         A.mode = 0; A.depth = c->ws.tmp_depth;

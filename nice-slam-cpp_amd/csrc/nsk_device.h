@@ -1010,6 +1010,36 @@ __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f
 // is resident: the host uses this mode only while the grid has at most one workgroup per CU), each workgroup then finds
 // 10 x the lower median by rank counting.  One launch instead of composite + k_median_thr + composite (Tracker.cpp:67-71).
 #define NSK_MEDIAN_FUSED_MAX 1024         // rays (LDS copy of the residuals; the host also caps the grid at one workgroup per CU)
+// The target-th smallest of rs[0..n4) (all >= 0, padding = +inf) by bisection on the bit pattern (non-negative floats order like their
+// patterns): 31 counting passes over a few registers per thread, one barrier each; every thread of the NT-thread workgroup must call it.
+// Until round 3 every workgroup of k_composite mode 4 ranked every residual against every other -- N^2 / 4 LDS reads per workgroup, 200 us
+// of that launch at 1000 rays (tools/track_times.py).
+template <int NT, int MAXN>
+__device__ __forceinline__ float median_select(const float* __restrict__ rs, int n4, int target)
+{
+    constexpr int PER = (MAXN + NT - 1) / NT;
+    __shared__ int part[2][NT / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned u[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { const int i = threadIdx.x + e * NT; u[e] = i < n4 ? __float_as_uint(rs[i]) : 0xffffffffu; }
+    unsigned ans = 0u;
+    for (int bit = 30; bit >= 0; --bit) {
+        const unsigned cand = ans | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) cnt += u[e] < cand ? 1 : 0;
+        cnt = (int)wave_sum((float)cnt);
+        if (lane == 0) part[bit & 1][wave] = cnt;
+        __syncthreads();
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot += part[bit & 1][w];
+        if (tot <= target) ans = cand;
+    }
+    return __uint_as_float(ans);
+}
+
 template <int RPW>           // rays (waves) per workgroup; bid / nb: this role's workgroup index and count inside the launch
 __device__ __forceinline__ void composite_body(const CompArgs& A, int bid, int nb)
 {
@@ -1095,16 +1125,8 @@ __device__ __forceinline__ void composite_body(const CompArgs& A, int bid, int n
         }
         __syncthreads();
         const int target = (max(s_valid, 1) - 1) / 2;          // torch.median: the lower median of the valid residuals
-        for (int i = threadIdx.x; i < A.N; i += 64 * RPW) {         // rank of residual i in the order (value, index); four comparisons per LDS read
-            const float v = rs[i];
-            int rank = 0;
-            for (int k = 0; k < N4; k += 4) {
-                const f4 u = *reinterpret_cast<const f4*>(rs + k);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rank += (u[q] < v || (u[q] == v && k + q < i)) ? 1 : 0;
-            }
-            if (rank == target) s_thr = 10.f * v;
-        }
+        const float med = median_select<64 * RPW, NSK_MEDIAN_FUSED_MAX>(rs, N4, target);
+        if (threadIdx.x == 0) s_thr = 10.f * med;
         __syncthreads();
         thr_here = s_thr;
         if (threadIdx.x == 0) {

@@ -9,6 +9,8 @@ sc = scenes.make_scene(42)
 r = scenes.make_rays(7, N, sc["bound"], H=680, W=1200, n_frames=1, edge=20)
 cu = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
 ctx = pkg.Context(0); ctx.set_render_opts(); ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
+for kv in sys.argv[2:]:          # key=value pairs for nsk_set_tuning (e.g. no_fused_median=1)
+    k, v_ = kv.split("="); ctx.set_tuning(k, int(v_))
 c2w = r["c2w"][0]
 R = c2w[:3, :3].astype(np.float64); qw = np.sqrt(max(1e-12, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
 q = np.array([qw, (R[2, 1] - R[1, 2]) / (4 * qw), (R[0, 2] - R[2, 0]) / (4 * qw), (R[1, 0] - R[0, 1]) / (4 * qw)])

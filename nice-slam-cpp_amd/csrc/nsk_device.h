@@ -1102,6 +1102,8 @@ __device__ __forceinline__ void composite_body(const CompArgs& A, int bid, int n
         // The residuals travel as device-scope atomics (they are written through to the coherence point) and the counter is bumped only
         // after this workgroup's stores have been acknowledged (vmcnt): no release / acquire fence, which on this part writes back and
         // invalidates the whole L2 of the XCD (measured: the launch took 22 us with __threadfence(), three launches took 8)
+        // (round 3 tried the residual slots themselves as the barrier -- -1 between launches, every thread polling the slot it copies: 24 us
+        // against 21 at 200 rays, 44 against 27 at 1000: ten thousand pollers on the same few lines cost more than the two round trips saved)
         if (lane == 0) __hip_atomic_store(&A.resid[n], kept ? fabsf(A.gt_depth[n] - D) : NSK_INF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // masked rays sort to the end (k_median_thr)
         if (threadIdx.x == 0) { s_thr = NSK_INF; s_valid = 0; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

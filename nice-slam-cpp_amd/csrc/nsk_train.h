@@ -109,21 +109,40 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h01, u
     m01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){r0, r1}, bf2));
 }
 
-// transpose one D-layout quad (16 feature rows x this wave's 16 samples) into the panel at row `row0`: 16-bit stores (low / high half)
+// transpose one D-layout quad (16 feature rows x this wave's 16 samples) into the panel at row `row0`.
+// Until round 3 every lane stored its four rows as 16-bit values, eight ds_write_b16 per quad: an LDS store takes its four cycles whatever its
+// width, 368 of them per wave and iteration kept the put phases on the LDS store path (11.8 k cycles CU-wide, tools/exp_ph3.py).  Now the two
+// lanes of adjacent samples share the work: the even lane keeps rows 0, 1 of both samples, the odd lane rows 2, 3 (one DPP exchange of the dword
+// the partner needs, two byte permutes), and each stores two 32-bit words per plane -- half the store instructions for +6 vector instructions.
+__device__ __forceinline__ void pair_words(unsigned v01, unsigned v23, bool odd, unsigned selA, unsigned selB, unsigned& wA, unsigned& wB)
+{
+    const unsigned keep = odd ? v23 : v01, send = odd ? v01 : v23;
+    const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]: the neighbouring sample's lane
+    wA = __builtin_amdgcn_perm(keep, recv, selA);      // first kept row:  (even sample | odd sample << 16)
+    wB = __builtin_amdgcn_perm(keep, recv, selB);      // second kept row
+}
+struct PairSel { bool odd; unsigned selA, selB; int rowoff, col2; };
+__device__ __forceinline__ PairSel pair_sel(int wave, int lane)
+{
+    PairSel P;
+    P.odd = (lane & 1) != 0;
+    P.selA = P.odd ? 0x05040100u : 0x01000504u; P.selB = P.odd ? 0x07060302u : 0x03020706u;
+    P.rowoff = 4 * (lane >> 4) + (P.odd ? 2 : 0);
+    P.col2 = (16 * wave + (lane & 14)) * 2;
+    return P;
+}
 __device__ __forceinline__ void pn_put(char* __restrict__ pn, int moff, int row0, int wave, int lane, f4 x, float us = 1.f)
 {
     x *= us;                                // (gradients of a chain on fp16 pieces: the sample's scale comes off here)
-    const int j = lane & 15, g = lane >> 4;
-    char* ph = pn + (row0 + 4 * g) * PN_RB + (16 * wave + j) * 2;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        unsigned h01, m01;
-        split2_pair(x[2 * p], x[2 * p + 1], h01, m01);
-        *reinterpret_cast<unsigned short*>(ph + (2 * p) * PN_RB) = (unsigned short)h01;
-        *reinterpret_cast<unsigned short*>(ph + (2 * p + 1) * PN_RB) = (unsigned short)(h01 >> 16);
-        *reinterpret_cast<unsigned short*>(ph + moff + (2 * p) * PN_RB) = (unsigned short)m01;
-        *reinterpret_cast<unsigned short*>(ph + moff + (2 * p + 1) * PN_RB) = (unsigned short)(m01 >> 16);
-    }
+    const PairSel P = pair_sel(wave, lane);
+    char* ph = pn + (row0 + P.rowoff) * PN_RB + P.col2;
+    unsigned h01, m01, h23, m23, a, b;
+    split2_pair(x[0], x[1], h01, m01);
+    split2_pair(x[2], x[3], h23, m23);
+    pair_words(h01, h23, P.odd, P.selA, P.selB, a, b);
+    *reinterpret_cast<unsigned*>(ph) = a; *reinterpret_cast<unsigned*>(ph + PN_RB) = b;
+    pair_words(m01, m23, P.odd, P.selA, P.selB, a, b);
+    *reinterpret_cast<unsigned*>(ph + moff) = a; *reinterpret_cast<unsigned*>(ph + moff + PN_RB) = b;
 }
 
 // Half-word masks of a layer's eight ReLU bits: dword d covers elements 2d (low half) and 2d + 1 (high half) of the lane's block -- the
@@ -153,27 +172,23 @@ __device__ __forceinline__ H2 mask_block_h4(const H2& x, const Mask4& M)
 }
 // pn_put of a gradient quad x (rows row1..) TOGETHER with its ReLU-masked copy (rows row2..): g_a = ReLU'(.) g_h, and the pieces of a zero
 // are zeros, so the masked quad's pieces are the quad's pieces ANDed with the half-word masks -- one scale and one split for both.
-__device__ __forceinline__ void pn_put_masked(char* __restrict__ pn, int moff, int row1, int row2, int wave, int lane, f4 x, float us, unsigned m01, unsigned m23)
+__device__ __forceinline__ void pn_put_masked(char* __restrict__ pn, int moff, int row1, int row2, int wave, int lane, f4 x, float us, unsigned k01, unsigned k23)
 {
     x *= us;
-    const int j = lane & 15, g = lane >> 4;
-    char* p1 = pn + (row1 + 4 * g) * PN_RB + (16 * wave + j) * 2;
+    const PairSel P = pair_sel(wave, lane);
+    char* p1 = pn + (row1 + P.rowoff) * PN_RB + P.col2;
     char* p2 = p1 + (row2 - row1) * PN_RB;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        unsigned h01, m01_;
-        split2_pair(x[2 * p], x[2 * p + 1], h01, m01_);
-        const unsigned k = p ? m23 : m01;
-        const unsigned ha = h01 & k, ma = m01_ & k;
-        *reinterpret_cast<unsigned short*>(p1 + (2 * p) * PN_RB) = (unsigned short)h01;
-        *reinterpret_cast<unsigned short*>(p1 + (2 * p + 1) * PN_RB) = (unsigned short)(h01 >> 16);
-        *reinterpret_cast<unsigned short*>(p1 + moff + (2 * p) * PN_RB) = (unsigned short)m01_;
-        *reinterpret_cast<unsigned short*>(p1 + moff + (2 * p + 1) * PN_RB) = (unsigned short)(m01_ >> 16);
-        *reinterpret_cast<unsigned short*>(p2 + (2 * p) * PN_RB) = (unsigned short)ha;
-        *reinterpret_cast<unsigned short*>(p2 + (2 * p + 1) * PN_RB) = (unsigned short)(ha >> 16);
-        *reinterpret_cast<unsigned short*>(p2 + moff + (2 * p) * PN_RB) = (unsigned short)ma;
-        *reinterpret_cast<unsigned short*>(p2 + moff + (2 * p + 1) * PN_RB) = (unsigned short)(ma >> 16);
-    }
+    unsigned h01, m01, h23, m23, a, b;
+    split2_pair(x[0], x[1], h01, m01);
+    split2_pair(x[2], x[3], h23, m23);
+    pair_words(h01, h23, P.odd, P.selA, P.selB, a, b);
+    *reinterpret_cast<unsigned*>(p1) = a; *reinterpret_cast<unsigned*>(p1 + PN_RB) = b;
+    pair_words(m01, m23, P.odd, P.selA, P.selB, a, b);
+    *reinterpret_cast<unsigned*>(p1 + moff) = a; *reinterpret_cast<unsigned*>(p1 + moff + PN_RB) = b;
+    pair_words(h01 & k01, h23 & k23, P.odd, P.selA, P.selB, a, b);
+    *reinterpret_cast<unsigned*>(p2) = a; *reinterpret_cast<unsigned*>(p2 + PN_RB) = b;
+    pair_words(m01 & k01, m23 & k23, P.odd, P.selA, P.selB, a, b);
+    *reinterpret_cast<unsigned*>(p2 + moff) = a; *reinterpret_cast<unsigned*>(p2 + moff + PN_RB) = b;
 }
 
 // the tiles of one phase owned by this wave, accumulated over the panel's 128 samples

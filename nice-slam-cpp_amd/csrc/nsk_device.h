@@ -160,6 +160,13 @@ __device__ __forceinline__ int cell_index(int GX, int GY, int GZ, const float* b
 #define NSK_SAMPLE_RAYS 8           // rays (waves) per workgroup of k_sample (16: 19.6 us at 5000 rays, 8: 18.1, 4: 20.9; 1000 rays: 11.5 / 10.6 / 12.3)
 #endif
 #define NSK_SAMPLE_TABLE 2048       // slots of its cell table (>= 2 x NSK_SAMPLE_RAYS x 64 keeps probing short)
+#ifdef NSK_EXPERIMENT
+extern __device__ unsigned long long nsk_dbg_ts[2][1024][4];
+// stamps of one workgroup of the sampling (tools/exp_sample.py): slot k of the unused tail of the forward's stamp array
+#define NSK_SS(k) do { if (bid == 300 && threadIdx.x == 0) nsk_dbg_ts[0][1000 + (k)][0] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NSK_SS(k)
+#endif
 struct SampArgs {
     RParams R; int N, S;
     const float* rays_o; const float* rays_d; const float* gt_depth; float gtmax_host; const float* gtmax_dev; const uint8_t* keep;
@@ -181,6 +188,7 @@ __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
     const int n = bid * NSK_SAMPLE_RAYS + wave;
     const bool active = n < N;                          // whole waves; inactive ones only take part in the barriers below
     const int nc = active ? n : N - 1;
+    NSK_SS(0);
     const bool has_gt = gt_depth != nullptr;
     const int ns = R.n_samples;
     const int nsurf = S - ns;
@@ -250,11 +258,13 @@ __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
         z = sh2[wave][lane];
     }
     if (active && lane < S) z_out[(size_t)n * S + lane] = z;
+    NSK_SS(1);
     if (!skey) return;                                                      // uniform over the launch
     // ---- cell keys and ranks for the cell sort -----------------------------------------------------------------------------
     if (bid == 0 && threadIdx.x == 0) hist[-1] = 0;                 // the bump cursor of k_sort_scan (one int in front of the histogram)
     for (int i = threadIdx.x; i < NSK_SAMPLE_TABLE; i += 64 * NSK_SAMPLE_RAYS) { tkey[i] = -1; tcnt[i] = 0; }
     if (threadIdx.x == 0) nlist = 0;
+    NSK_SS(2);
     int cell = -1;
     if (active && lane < S) {
         const float px = add_rn(ox, mul_rn(dx, z)), py = add_rn(oy, mul_rn(dy, z)), pz = add_rn(oz, mul_rn(dz, z));   // = sample_finish
@@ -273,6 +283,7 @@ __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
     // runs of the workgroup's rays are first merged in an LDS table (rays of one frame all start in the cells around the camera,
     // and a thousand adds on one 64-byte line take 25 us: same-line atomics serialise at the memory side), then every
     // distinct cell of the workgroup makes ONE returning add on the global histogram.
+    NSK_SS(3);
     const int prev = __shfl_up(cell, 1);
     const bool leader = active && lane < S && (lane == 0 || prev != cell);
     const unsigned long long lead = __builtin_amdgcn_ballot_w64(leader);
@@ -293,14 +304,18 @@ __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
         slot = (int)h;
         off = atomicAdd(&tcnt[h], next - lane);
     }
+    NSK_SS(4);
     __syncthreads();
+    NSK_SS(5);
     // one returning add per distinct cell, ONE per thread (at most 64 x rays distinct cells): walking the table itself, a thread met up to
     // four occupied slots and made their adds one after the other -- two to three round trips of the 18 us this launch took at 5000 rays
     if ((int)threadIdx.x < nlist) { const int i = tlist[threadIdx.x]; tbase[i] = atomicAdd(hist + hist_slot(tkey[i], ncell2), tcnt[i]); }
     __syncthreads();
+    NSK_SS(6);
     int base = leader ? tbase[slot] + off : 0;
     base = __shfl(base, start);
     if (active && lane < S) { skey[(size_t)n * S + lane] = cell; srank[(size_t)n * S + lane] = base + (lane - start); }
+    NSK_SS(7);
 }
 __global__ __launch_bounds__(64 * NSK_SAMPLE_RAYS) void k_sample(SampArgs P) { sample_body(P, blockIdx.x); }
 

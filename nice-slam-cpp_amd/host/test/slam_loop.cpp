@@ -78,6 +78,9 @@ int main(int argc, char** argv)
             }
             std::printf("frame %d: track loss %.4f, |t_est - t_gt| %.4f m%s\n", i, tl.back(),
                         (est[i].index({Slice(None, 3), 3}) - gt.index({Slice(None, 3), 3})).norm().item<float>(), i % every == 0 ? ", mapped" : "");
+            // device time of the frame's loops (stream-synchronised walls the classes keep): the Tracker's whole iteration loop, the Mapper's mean iteration
+            if (i > 0) std::printf("time frame %d: tracker loop %.1f us\n", i, tracker.last_run_us);
+            if (i % every == 0) std::printf("time frame %d: mapper iteration %.1f us\n", i, mapper.last_iter_us);
         }
         save_npy(out + "est_poses.npy", torch::stack(est)); save_npy(out + "gt_poses.npy", torch::stack(gts));
         save_npy(out + "track_loss.npy", torch::tensor(tl)); save_npy(out + "map_loss.npy", torch::tensor(ml));

@@ -465,3 +465,66 @@ def test_slam_loop_over_a_tum_sequence(tmp_path):
     for k in ("grid_middle", "grid_fine", "grid_color"):
         g = np.load(out / (k + ".npy"))
         assert np.isfinite(g).all() and np.abs(g).max() > 0.02                                     # the map moved away from its N(0, 0.01) init
+
+
+def test_slam_loop_at_the_reference_config_sizes(tmp_path, capsys):
+    """K5 at the sizes config/nice_slam.yaml states, through the C++ classes: 640 x 480 frames (TUM fr1 intrinsics), Tracker 200 pixels x 10
+    iterations on every frame, Mapper 1000 pixels x 1500 iterations on the first frame and x 60 on every fifth, window 5, frustum feature
+    selection, BA on (it starts with the fifth keyframe: not reached in six frames).  The decoders are random and the oracle cannot walk
+    1 560 iterations of 48 000 samples in test time, so beyond "runs, finite, the pose stays near the truth, the map moved" this records what
+    the loop costs on the device: the Tracker's ten iterations and the Mapper's mean iteration (printed)."""
+    from test_host_io import _png
+    exe = os.path.join(ROOT, "nice-slam-cpp_amd", "host", "slam_loop")
+    if not os.path.exists(exe):
+        pytest.fail("slam_loop is not built (run __graft_entry__.build())")
+    seq = tmp_path / "tum"
+    (seq / "rgb").mkdir(parents=True); (seq / "depth").mkdir()
+    H, W, fx, fy, cx, cy = 480, 640, 517.3, 516.5, 318.6, 255.3
+    bound = np.array([[-2.0, 2.0], [-1.5, 1.5], [-2.0, 2.2]], np.float32)
+    flip = np.diag([1.0, -1.0, -1.0, 1.0])
+    F = 6
+    gts = []
+    with open(seq / "rgb.txt", "w") as fr, open(seq / "depth.txt", "w") as fd, open(seq / "groundtruth.txt", "w") as fg:
+        for i in range(F):
+            t = 1.0 + 0.1 * i
+            p_tum = np.eye(4); p_tum[:3, 3] = [0.01 * i, 0.005 * i, 0.008 * i]
+            c2w = (p_tum @ flip).astype(np.float32)
+            gts.append(c2w)
+            depth = scenes.frame_depth_image(bound, c2w, H, W, fx, fy, cx, cy)
+            jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+            dirs = np.stack([(ii - cx) / fx, -(jj - cy) / fy, -np.ones_like(ii, dtype=np.float64)], -1) @ c2w[:3, :3].T.astype(np.float64)
+            hit = c2w[:3, 3] + dirs * depth[..., None]
+            col = np.clip(255 * (0.5 + 0.5 * np.sin(hit * np.array([1.3, 2.1, 0.7]))), 0, 255).astype(np.uint8)
+            _png(str(seq / "rgb" / ("%.6f.png" % t)), col)
+            _png(str(seq / "depth" / ("%.6f.png" % t)), np.round(depth * 5000).astype(np.uint16))
+            fr.write("%.6f rgb/%.6f.png\n" % (t, t)); fd.write("%.6f depth/%.6f.png\n" % (t, t))
+            fg.write("%.6f %.9g %.9g %.9g 0 0 0 1\n" % ((t,) + tuple(p_tum[:3, 3])))
+    (seq / "bound.txt").write_text(" ".join("%g" % v for v in bound.reshape(-1)))
+    ns, cf = tmp_path / "ns.yaml", tmp_path / "cf.yaml"
+    y = NS_YAML
+    for a, b in (("  ignore_edge_W: 4", "  ignore_edge_W: 20"), ("  ignore_edge_H: 4", "  ignore_edge_H: 20"), ("  pixels: 200\n  iters: 5", "  pixels: 200\n  iters: 10"),
+                 ("  BA: False", "  BA: True"), ("  keyframe_every: 2", "  keyframe_every: 50"), ("  pixels: 500\n  iters_first: 30\n  iters: 10", "  pixels: 1000\n  iters_first: 1500\n  iters: 60")):
+        assert y.count(a) == 1, a
+        y = y.replace(a, b)
+    ns.write_text(y)
+    cf.write_text("mapping:\n  pixels: 1000\ncam:\n  H: %d\n  W: %d\n  fx: %g\n  fy: %g\n  cx: %g\n  cy: %g\n" % (H, W, fx, fy, cx, cy))
+    out = tmp_path / "out"; out.mkdir()
+    r = subprocess.run([exe, "tum", str(seq), str(ns), str(cf), str(out), str(F), "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "slam_loop ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    times = [l for l in r.stdout.splitlines() if l.startswith("time frame")]
+    with capsys.disabled():
+        print("\nK5 at the reference config's sizes (640 x 480, Tracker 200 x 10, Mapper 1000 x 1500 / 60):")
+        for l in times:
+            print("  " + l)
+    trk = [float(l.split("tracker loop")[1].split("us")[0]) for l in times if "tracker loop" in l]
+    mp = [float(l.split("mapper iteration")[1].split("us")[0]) for l in times if "mapper iteration" in l]
+    assert len(trk) == F - 1 and len(mp) == 2
+    assert max(trk[1:]) < 5000 and max(mp) < 2000                                                   # ten Tracker iterations < 5 ms, a Mapper iteration < 2 ms
+    est, gt = np.load(out / "est_poses.npy"), np.load(out / "gt_poses.npy")
+    assert est.shape == (F, 4, 4) and np.allclose(gt, np.stack(gts), atol=1e-5)
+    tl, ml = np.load(out / "track_loss.npy"), np.load(out / "map_loss.npy")
+    assert tl.shape == (F,) and ml.shape == (2,) and np.isfinite(tl).all() and np.isfinite(ml).all() and (ml > 0).all() and (tl[1:] > 0).all()
+    assert np.isfinite(est).all() and np.linalg.norm(est[:, :3, 3] - gt[:, :3, 3], axis=1).max() < 0.15
+    for k in ("grid_middle", "grid_fine", "grid_color"):
+        g = np.load(out / (k + ".npy"))
+        assert np.isfinite(g).all() and np.abs(g).max() > 0.02

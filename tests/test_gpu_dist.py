@@ -188,7 +188,7 @@ def test_deterministic_debug_mode_is_bit_reproducible():
     assert out["det_a"][2] == out["det_b"][2]
 
 
-@pytest.mark.parametrize("case", ["color-sorted", "color-unsorted", "fine-sorted", "color-late", "color-interrupted", "color-off"])
+@pytest.mark.parametrize("case", ["color-sorted", "color-unsorted", "fine-sorted", "color-late", "color-interrupted", "color-off", "color-rays"])
 def test_map_prepare_gives_the_unprepared_steps(case):
     """nsk_map_prepare (the next batch's sampling rides in this step's composite launch, the cell sort's offsets in the backward launch, its
     placement in the Adam launch): five mapping steps over two alternating batches with every next batch registered before the step, against
@@ -196,7 +196,8 @@ def test_map_prepare_gives_the_unprepared_steps(case):
     sampling launches of their own.  Cases: cell-sorted and ray-order steps; the fine stage (no trainable decoder: the offsets ride in
     k_decode_bwd_frozen); "late" = registered AFTER the step (nothing left to ride in: sampled at the start of its own step, as before);
     "interrupted" = another batch is rendered between the step and the optimiser (the histogram is needed: the remaining stages are
-    launched at once); "off" = nsk_set_tuning("no_piggyback", 1)."""
+    launched at once); "off" = nsk_set_tuning("no_piggyback", 1); "rays" = steps with ray gradients (bundle adjustment: the backward is the
+    ray-gradient kernel, which carries nothing -- the sampling rides, the sort is launched at the start of the batch's own step)."""
     stage = "fine" if case.startswith("fine") else "color"
     sc = scenes.make_scene(11, grid_std=0.05)
     batches = []
@@ -214,6 +215,10 @@ def test_map_prepare_gives_the_unprepared_steps(case):
         loss = torch.zeros(1, device="cuda")
         losses, names = [], None
         flags = 3 if stage == "color" else 1
+        g_rays = None
+        if case.endswith("rays"):
+            flags |= 4
+            g_rays = (torch.zeros(400, 3, device="cuda"), torch.zeros(400, 3, device="cuda"))
         with torch.cuda.stream(ctx.tstream):
             for i in range(5):
                 ro, rd, gd, gc, gm = batches[i % 2]
@@ -222,7 +227,7 @@ def test_map_prepare_gives_the_unprepared_steps(case):
                     ctx.profile_begin()
                 if prepare and not case.endswith("late"):
                     ctx.map_prepare(stage, n[0], n[1], n[2], n[4], flags=flags)
-                ctx.map_step(stage, ro, rd, gd, gc, gm, 0.2, stage == "color", flags=flags, loss=loss)
+                ctx.map_step(stage, ro, rd, gd, gc, gm, 0.2, stage == "color", flags=flags, loss=loss, g_rays=g_rays)
                 if prepare and case.endswith("late"):
                     ctx.map_prepare(stage, n[0], n[1], n[2], n[4], flags=flags)
                 if case.endswith("interrupted"):
@@ -238,6 +243,8 @@ def test_map_prepare_gives_the_unprepared_steps(case):
         assert "sample" not in n1 and "cell_sort" not in n1, n1          # everything rode along
     elif case == "color-interrupted":
         assert "cell_sort" in n1                                          # (the render's own sampling is in there as well)
+    elif case == "color-rays":
+        assert "sample" not in n1 and "cell_sort" in n1
     else:
         assert "sample" in n1
     assert np.allclose(l0, l1, rtol=1e-5)

@@ -420,10 +420,10 @@ def test_tracking_steps_match_oracle(oracle32, oracle64):
     print("tracking: grad err hip %.2e oracle32 %.2e | pose err hip %.2e oracle32 %.2e" % (e_g, e_g_ref, e_p, e_p_ref))
 
 
-@pytest.mark.parametrize("n_rays,masked", [(200, False), (37, True), (1023, False), (1500, False)])
+@pytest.mark.parametrize("n_rays,masked", [(200, False), (37, True), (1023, False), (1500, False), (1, False), (2, True), (5, False), (1000, True)])
 def test_tracker_median_in_the_composite_launch(n_rays, masked):
-    """Tracker.cpp:67-71: the 10 x median threshold computed inside the loss launch (k_composite mode 4: residuals, grid barrier, rank
-    counting) gives the bits of the three-launch form (composite, k_median_thr, composite); ray counts that are not a multiple of the
+    """Tracker.cpp:67-71: the 10 x median threshold computed inside the loss launch (k_composite mode 4: residuals, grid barrier, selection
+    by bisection on the bit pattern) gives the bits of the three-launch form (composite, k_median_thr, composite); ray counts that are not a multiple of the
     four rays of a workgroup, a ray mask, and a batch above the fused form's limit (1500 rays: both runs take the three launches)"""
     sc = _scene(33, grid_std=0.3)
     rays = scenes.make_rays(34, n_rays, sc["bound"], n_frames=1, zero_frac=0.1)

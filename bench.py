@@ -472,7 +472,7 @@ def main():
                                  "multiple of the gradient; the trainable decoder's weight-gradient panels = two bf16 pieces (16 bits, fp32 sums); fp32 MFMA "
                                  "for the grid-gradient scatter",
                        "frustum_feature_selection": res["mask_frac"] is not None, "marked_voxel_fraction": res["mask_frac"],
-                       "exchange": exchange, "pipeline": pipeline,
+                       "exchange": exchange, "pipeline": pipeline, "launches_per_step": (4 if pipeline else 7) + (3 if world > 1 else 0),
                        "pipeline_detail": ("every timed step holds one batch's sampling + cell sort, forward, loss, backward and Adam; the sampling and sort are those of the "
                                            "NEXT batch, registered before the step (nsk_map_prepare), and ride in this step's composite / backward / Adam launches "
                                            "instead of three launches of their own in front of the forward") if pipeline else "every step samples and sorts its own batch first",

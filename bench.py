@@ -31,8 +31,19 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_16BIT_MFMA_TFLOPS = 2500.0    # same guide, dense BF16 / FP16 MFMA peak
 PEAK_HBM_GBS = 8000.0              # same guide, HBM3E peak
-PMC_FILE = "r03_pmc_hbm.json"      # profiles/: FETCH_SIZE / WRITE_SIZE passes of the default command (tools/profile_round.sh)
-PMC_SQ_FILE = "r03_pmc_sq.json"    # profiles/: SQ passes (MFMA busy cycles ...) + GRBM_GUI_ACTIVE of the same command
+# committed rocprofv3 counter passes of this same (default) command, newest first (tools/profile_round.sh): FETCH_SIZE / WRITE_SIZE and the
+# SQ passes (instruction counts, MFMA busy cycles, waits ...) + GRBM_GUI_ACTIVE.  bench.py cannot collect counters itself; what it replays from
+# these files is labelled "counters_from" in the JSON line -- the durations beside them are always this run's HIP events.
+PMC_FILES = ("r04_pmc_hbm.json", "r03_pmc_hbm.json")
+PMC_SQ_FILES = ("r04_pmc_sq.json", "r03_pmc_sq.json")
+KERNEL_PREFIX = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "void k_decode_fwd_multi_bf16"}
+
+
+def _first_profile(names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return n
+    return None
 
 # algorithmic MACs per sample of each decoder role (DESIGN.md "Kernels")
 MAC = {
@@ -191,7 +202,7 @@ TUNE = []
 
 
 def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, frustum=True, matmul_mode=None, pipeline=False,
-                 comm=None, rays_total=None):
+                 comm=None, rays_total=None, repeats=1):
     """time `steps` mapping iterations of workload `wl` at `N` rays per GPU (rays_total: a FIXED batch of that many rays sharded over
     the ranks instead -- strong scaling); returns dict(dt, prof, loss, scene, pool, ...).  comm: an RCCL communicator for the C-ABI
     exchange (nsk_allreduce_grads), None = torch.distributed on the packed buffer"""
@@ -278,22 +289,28 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
                 ctx.graph_launch(gids[i % len(gids)])
         for i in range(warmup):
             step(i)
-        torch.cuda.synchronize()
+        # The timed region is EXACTLY `steps` steps between barrier + synchronize on both sides, maximum over the ranks -- and that block is
+        # run `repeats` times back to back, the MEDIAN block being the one reported: a 20-step block of a 0.4 ms step is 8 ms behind a few
+        # warm-up steps, clocks and caches are not settled, and the driver's 20-step line read 7-10 % below a 200-step run of the same box.
+        blocks = []
+        for rep in range(max(1, repeats)):
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(warmup + rep * steps + i)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            blocks.append(time.perf_counter() - t0)
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor(blocks, device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t)
+            blocks = [float(x) for x in t]
+        dt = float(np.median(blocks))
         # per-kernel durations: HIP events recorded on the context's stream around every launch (same steps again)
         ctx.profile_begin()
         timing[0] = True
@@ -312,7 +329,7 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
     marked = None
     if mask_frac is not None:
         marked = sum(mask_frac[k] * sc["grids"][k].size for k in STAGE_DECODERS[stage])
-    out = dict(dt=dt, prof=prof, loss=final_loss, sc=sc, pool=pool, lr=lr, w_color=w_color, slab_floats=int(ctx.grad_slab().numel()),
+    out = dict(dt=dt, blocks=blocks, prof=prof, loss=final_loss, sc=sc, pool=pool, lr=lr, w_color=w_color, slab_floats=int(ctx.grad_slab().numel()),
                exchange_floats=int(xn[0]), mask_frac=mask_frac, marked_params=marked, rays_per_gpu=N)
     ctx.close()
     return out
@@ -322,16 +339,35 @@ def sq_profile(kernel_prefix):
     """MFMA-busy share of the dominant kernel from the committed SQ counter passes of this same command (profiles/, tools/profile_round.sh):
     SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x the kernel's cycles); the kernel's cycles = GRBM_GUI_ACTIVE / 8 XCDs where that
     counter was collected, else duration x 2.4 GHz (an upper bound on the cycles, so a lower bound on the share)"""
-    path = os.path.join(ROOT, "profiles", PMC_SQ_FILE)
-    if not os.path.exists(path):
+    name = _first_profile(PMC_SQ_FILES)
+    if name is None:
         return None
-    pmc = json.load(open(path))
+    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
     get = lambda c: next((v for k, v in pmc.items() if k.startswith(kernel_prefix) and k.endswith("|" + c)), None)
     busy, gui = get("SQ_VALU_MFMA_BUSY_CYCLES"), get("GRBM_GUI_ACTIVE")
     if busy is None:
         return None
     return {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui, "SQ_WAIT_ANY": get("SQ_WAIT_ANY"), "SQ_WAVE_CYCLES": get("SQ_WAVE_CYCLES"),
-            "SQ_LDS_BANK_CONFLICT": get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": get("SQ_LDS_IDX_ACTIVE"), "file": "profiles/" + PMC_SQ_FILE}
+            "SQ_INSTS_VALU": get("SQ_INSTS_VALU"), "SQ_INSTS_MFMA": get("SQ_INSTS_MFMA"), "SQ_INSTS_VMEM": get("SQ_INSTS_VMEM"), "SQ_INSTS_LDS": get("SQ_INSTS_LDS"),
+            "SQ_LDS_BANK_CONFLICT": get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": get("SQ_LDS_IDX_ACTIVE"), "file": "profiles/" + name}
+
+
+def counter_fracs(sq, dur_s):
+    """what bounds a decoder kernel, from its counters: SIMD-cycles = 4 SIMDs x 256 CUs x the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs, else
+    duration x 2.4 GHz); mfma_busy = matrix-pipe busy cycles / SIMD-cycles; issue_frac = (4 cycles per non-MFMA vector instruction + the
+    matrix pipe's busy cycles) / SIMD-cycles -- matrix and vector instructions of a SIMD serialise (tools/ubench/interleave.hip);
+    wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of a wave's resident cycles spent waiting on a counter)"""
+    cycles = sq["GRBM_GUI_ACTIVE"] / 8.0 if sq.get("GRBM_GUI_ACTIVE") else dur_s * 2.4e9
+    simd = 4.0 * 256.0 * cycles
+    out = {"simd_cycles": simd, "mfma_busy": sq["SQ_VALU_MFMA_BUSY_CYCLES"] / simd}
+    if sq.get("SQ_INSTS_VALU") is not None and sq.get("SQ_INSTS_MFMA") is not None:
+        out["valu_issue_frac"] = 4.0 * (sq["SQ_INSTS_VALU"] - sq["SQ_INSTS_MFMA"]) / simd
+        out["issue_frac"] = out["valu_issue_frac"] + out["mfma_busy"]
+    if sq.get("SQ_WAIT_ANY") is not None and sq.get("SQ_WAVE_CYCLES"):
+        out["wait_frac"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+    if sq.get("SQ_LDS_BANK_CONFLICT") is not None and sq.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_conflict_frac"] = sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]
+    return out
 
 
 def summarize(res, stage, N, steps, world, with_counters=False):
@@ -348,7 +384,11 @@ def summarize(res, stage, N, steps, world, with_counters=False):
     flops = 2.0 * alg[dom]["mac"] * M
     tf = flops / dom_s / 1e12
     products = alg[dom]["products"]
-    roof = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+    # "bound": the contract's vocabulary is hbm | mfma, and this launch is neither: its counters (committed passes, replayed below under
+    # "counters") say vector-instruction issue + latency -- `frac` stays the algorithmic fp32 FLOP rate over the fp32 matrix peak because the
+    # contract is fp32 arithmetic, but that peak is not what limits a chain run on 16-bit pieces (the forward exceeds it), so read
+    # issue_frac / wait_frac / mfma_busy / frac_16bit beside it
+    roof = {"bound": "valu-issue+latency", "contract_bound": "mfma", "kernel": dom, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
             "avg_launch_us": dom_s * 1e6, "alg_flops_per_launch": flops,
             # the same launch against what its own instruction mix allows: every fp32 multiply-add is `products` 16-bit matrix products
@@ -358,12 +398,19 @@ def summarize(res, stage, N, steps, world, with_counters=False):
             "alg_bytes_per_launch": float(alg[dom]["alg_bytes"]) * M, "hbm_frac_same_kernel": alg[dom]["alg_bytes"] * M / dom_s / 1e9 / PEAK_HBM_GBS,
             "impl_bytes_per_launch": float(alg[dom]["impl_bytes"]) * M, "mfma_busy": None}
     if with_counters:
-        prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "void k_decode_fwd_multi_bf16"}.get(dom)
-        sq = sq_profile(prefix) if prefix else None
+        sq = sq_profile(KERNEL_PREFIX[dom]) if dom in KERNEL_PREFIX else None
         if sq:
-            cycles = sq["GRBM_GUI_ACTIVE"] / 8.0 if sq["GRBM_GUI_ACTIVE"] else dom_s * 2.4e9
-            roof["mfma_busy"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * 256.0 * cycles)
+            roof.update({k: v for k, v in counter_fracs(sq, dom_s).items() if k != "simd_cycles"})
             roof["counters"] = sq
+            roof["counters_from"] = sq["file"] + " (committed rocprofv3 --pmc passes of this command, replayed: NOT measured in this run)"
+        other = fwd_name if dom == bwd_name else bwd_name      # the sibling launch on the same denominators
+        sq2 = sq_profile(KERNEL_PREFIX[other]) if other in KERNEL_PREFIX else None
+        if sq2:
+            o_s = prof[other][1] / prof[other][0] * 1e-3
+            o_tf = 2.0 * alg[other]["mac"] * M / o_s / 1e12
+            roof["sibling"] = dict({"kernel": other, "avg_launch_us": o_s * 1e6, "achieved": o_tf, "frac": o_tf / PEAK_FP32_MFMA_TFLOPS,
+                                    "frac_16bit": o_tf * alg[other]["products"] / PEAK_16BIT_MFMA_TFLOPS},
+                                   **{k: v for k, v in counter_fracs(sq2, o_s).items() if k != "simd_cycles"})
     step_s = res["dt"] / steps
     nparam = sum(res["sc"]["grids"][k].size for k in STAGE_DECODERS[stage])
     marked = res["marked_params"] if res.get("marked_params") is not None else nparam
@@ -372,7 +419,10 @@ def summarize(res, stage, N, steps, world, with_counters=False):
     alg_step = float(cnt["fwd"]["alg_bytes"] + cnt["bwd"]["alg_bytes"]) * M + ADAM_BYTES_PER_PARAM * marked
     impl_step = float(cnt["fwd"]["impl_bytes"] + cnt["bwd"]["impl_bytes"]) * M + ADAM_BYTES_PER_PARAM * marked
     step_flops = 2.0 * (cnt["fwd"]["mac"] + cnt["bwd"]["mac"]) * M + 1000.0 * M     # + sampling / compositing
-    return {"value": world * N / step_s, "ms_per_step": 1e3 * step_s, "roofline": roof,
+    blocks = res.get("blocks") or [res["dt"]]
+    return {"value": world * N / step_s, "ms_per_step": 1e3 * step_s, "repeats": len(blocks),
+            "block_ms_per_step": {"median": 1e3 * step_s, "min": 1e3 * min(blocks) / steps, "max": 1e3 * max(blocks) / steps, "first": 1e3 * blocks[0] / steps},
+            "roofline": roof,
             "step_rooflines": {"alg_bytes_per_step": alg_step, "hbm_frac": alg_step / step_s / 1e9 / PEAK_HBM_GBS,
                                "impl_bytes_per_step": impl_step, "adam_marked_params": marked,
                                "alg_flops_per_step": step_flops, "fp32_frac": step_flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS},
@@ -394,6 +444,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=9, help="the timed block of --steps steps is run this many times back to back; the median block is reported")
     ap.add_argument("--workload", default="K3", choices=["K3", "K2", "K4"])
     ap.add_argument("--rays", type=int, default=0, help="rays per GPU per step (0 = the workload's own count)")
     ap.add_argument("--stage", default="color")
@@ -440,25 +491,26 @@ def main():
     wl = W[args.workload]
     N = args.rays or wl["rays"]
     frustum = not args.no_frustum_mask
-    res = run_workload(wl, args.stage, N, args.steps, args.warmup, local, rank, world, dist, graph=args.graph, frustum=frustum, pipeline=pipeline, comm=comm)
+    res = run_workload(wl, args.stage, N, args.steps, args.warmup, local, rank, world, dist, graph=args.graph, frustum=frustum, pipeline=pipeline, comm=comm,
+                       repeats=args.repeats)
     headline_cfg = args.workload == "K3" and N == W["K3"]["rays"] and args.stage == "color" and frustum
     head = summarize(res, args.stage, N, args.steps, world, with_counters=headline_cfg) if rank == 0 else None
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same (default) command:
     # FETCH_SIZE and WRITE_SIZE collected in separate passes, KB; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950
-    pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
-    if rank == 0 and os.path.exists(pmc_path) and headline_cfg:
-        pmc = json.load(open(pmc_path))
-        prefix = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "void k_decode_fwd_multi_bf16"}.get(head["roofline"]["kernel"])
+    pmc_name = _first_profile(PMC_FILES)
+    if rank == 0 and pmc_name is not None and headline_cfg:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
+        prefix = KERNEL_PREFIX.get(head["roofline"]["kernel"])
         get = lambda c: next((v for k, v in pmc.items() if prefix and k.startswith(prefix) and k.endswith("|" + c)), None)
         if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
             head["roofline"]["traffic"] = (2.0 * get("FETCH_SIZE") + get("WRITE_SIZE")) * 1024.0
-            head["roofline"]["traffic_source"] = "profiles/" + PMC_FILE
+            head["roofline"]["traffic_source"] = "profiles/" + pmc_name + " (committed FETCH_SIZE / WRITE_SIZE passes of this command, replayed: NOT measured in this run)"
     out = None
     if rank == 0:
         out = {
             "metric": "mapping rays/sec (and ms/iter) on CoFusion room1 at 1/2/4/8 MI355X",
             "value": head["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": head["ms_per_step"], "repeats": head["repeats"], "block_ms_per_step": head["block_ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "dtype_detail": "fp32 storage and accumulation; matrix operands as two fp16 pieces (22 significant bits: forward, backward chains) or two "
                                             "bf16 pieces (16 bits: weight-gradient panels); fp32 MFMA for the grid-gradient scatter",
             "data": "synthetic",

@@ -47,6 +47,7 @@ extern "C" {
 #define NSK_GROUP_COLOR 4
 #define NSK_GROUP_CAMERA 5
 #define NSK_NUM_GROUPS 6
+#define NSK_MAX_POSE_FRAMES 32     /* frames of one nsk_pose_step_multi call (a mapping window; color_refine doubles mapping_window_size 5 -> 10) */
 
 typedef struct nsk_ctx nsk_ctx;
 
@@ -239,6 +240,20 @@ typedef struct nsk_frame_rays {
 int nsk_prepare_rays(nsk_ctx* ctx, int nframes, const nsk_frame_rays* h_frames, int rays_per_frame, int H0, int H1, int W0, int W1,
                      int H, int W, float fx, float fy, float cx, float cy, int mode, int32_t* d_pix_i, int32_t* d_pix_j,
                      float* d_gt_depth, float* d_gt_color, float* d_rays_o, float* d_rays_d, uint8_t* d_keep);
+/* nsk_pose_step for every frame of a mapping window in ONE launch (bundle adjustment, src/Mapper.cpp:305-329,366-368,467-489): frame f owns
+ * the rays [h_first[f], h_first[f] + h_count[f]) of the batch's pixel / ray-gradient arrays (a shard of the batch at N > 1: the part of
+ * the frame's rays that falls into this rank's range, possibly none) and the pose d_cams[8 f .. 8 f + 6] with moments d_m / d_v in the same
+ * layout; h_active[f] = 0 marks a frame whose pose is not optimised (the oldest frame of the window).
+ *   step >= 1: gradient + Adam step of every active pose, the arithmetic of nsk_pose_step frame by frame (one GPU);
+ *   step == 0: gradients only, d_g_cams[8 f + k] = d loss / d pose (zeros for inactive frames) -- the form for N > 1: register d_g_cams
+ *              with nsk_grad_extra so that it is summed over the ranks with the grid gradients, then step all poses at once with
+ *              nsk_adam_vector(8 * nframes, d_cams, d_g_cams, ...) (a zero gradient leaves a pose and its moments untouched).
+ * d_g_cams may be NULL for step >= 1; when given it has room for 8 * nframes + 8 floats and d_g_cams[8 nframes + 1] receives the number
+ * of rays of d_keep[0 .. n_keep) that take part (d_keep NULL: n_keep), the count a sharded step's ranks must add up to the batch's. */
+int nsk_pose_step_multi(nsk_ctx* ctx, int nframes, const int* h_first, const int* h_count, const uint8_t* h_active, const int32_t* d_pix_i,
+                        const int32_t* d_pix_j, float fx, float fy, float cx, float cy, int mode, const float* d_g_rays_o, const float* d_g_rays_d,
+                        float* d_cams, float* d_m, float* d_v, float lr, float beta1, float beta2, float eps, int step, float* d_g_cams,
+                        const uint8_t* d_keep, int n_keep);
 /* d loss / d c2w (12 floats, overwritten) from per-ray gradients */
 int nsk_rays_backward(nsk_ctx* ctx, int n, const int32_t* d_pix_i, const int32_t* d_pix_j, float fx, float fy,
                       float cx, float cy, int mode, const float* d_g_rays_o, const float* d_g_rays_d, float* d_g_c2w);
@@ -256,7 +271,13 @@ int nsk_inside_filter(nsk_ctx* ctx, int N, const float* d_rays_o, const float* d
  * (the call came after the step, another call needed the cell histogram in between, gt_depth_max < 0 with more than 8192 rays, a graph
  * capture) is launched at that point, as for an unprepared batch; a registered batch that is never asked for is dropped.  The rays and
  * the ground truth must stay valid and unchanged until their step has run, and must not depend on the running step's result (bundle
- * adjustment moves poses: do not prepare then).  Results are those of the unprepared step.  Everything runs on the context's stream. */
+ * adjustment moves poses: do not prepare then).  The same holds for the ray mask: what is remembered is the BUFFER installed with
+ * nsk_set_ray_mask at the time of this call, and its contents are read later -- when the batch's sampling runs inside the current step's
+ * composite launch, or at the batch's own step -- so the next batch's mask must live in a different buffer from the current step's mask and
+ * stay unchanged until the batch's step has run (two mask buffers used alternately, as Mapper::optimize_map does).
+ * Results are those of the unprepared step.  Everything runs on the context's stream.
+ * With hipGraphs: nsk_graph_begin first runs whatever of a prepared batch's sampling / sort is still pending (a capture never records it),
+ * nsk_graph_launch does the same and drops a prepared batch that lives in the buffer set the graph writes (its own step samples it again). */
 int nsk_map_prepare(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d, const float* d_gt_depth, float gt_depth_max,
                     unsigned flags);
 
@@ -266,6 +287,13 @@ int nsk_map_prepare(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const
  * nsk_render_backward leave the rays with d_keep == 0 out of max(gt_depth), the Tracker's median, the loss and every gradient --
  * the same sums the reference forms over the compacted batch, with no device-to-host round trip. */
 int nsk_set_ray_mask(nsk_ctx* ctx, const uint8_t* d_keep);
+/* A rank that renders a SHARD of a batch (rays shard over the GPUs of a node) still needs the batch-global max(gt_depth)
+ * (src/Renderer.cpp:76,93).  Every rank can hold the whole batch's ground-truth depths and keep bytes (they come from the same pixel draw:
+ * nsk_prepare_rays of the full window is one small launch), so no collective is needed: with a depth-max batch installed
+ * (d_gt_depth[n], d_keep[n] or NULL; n = 0 removes it) every step that is given gt_depth_max < 0 takes the maximum over THAT array
+ * -- one extra single-block launch in front of the sampling -- instead of over its own rays.  nsk_map_prepare remembers the batch
+ * installed at registration, like the ray mask. */
+int nsk_set_depth_max_batch(nsk_ctx* ctx, const float* d_gt_depth, const uint8_t* d_keep, int n);
 /* plain Adam on a caller-owned vector (camera 7-vectors: src/Tracker.cpp:103, src/Mapper.cpp:305-329) */
 int nsk_adam_vector(nsk_ctx* ctx, int n, float* d_p, const float* d_g, float* d_m, float* d_v, float lr, float beta1,
                     float beta2, float eps, int step);
@@ -308,6 +336,11 @@ int nsk_grad_slab(nsk_ctx* ctx, float** d_ptr, size_t* n_floats);
  * are rebuilt only when a mask changes (ascending voxel order, identical on every rank). */
 int nsk_grad_pack(nsk_ctx* ctx, float** d_ptr, size_t* n_floats);
 int nsk_grad_unpack(nsk_ctx* ctx);
+/* A caller-owned device vector that travels with the exchange: nsk_grad_pack appends its n_floats (a multiple of 4, 16-byte aligned) behind
+ * the loss floats, nsk_grad_unpack writes the sums back into it.  The C++ Mapper registers [8 floats per window frame: the bundle-adjustment
+ * pose gradients of nsk_pose_step_multi(step = 0) | loss | kept-ray count | 6 spare] so that a sharded BA iteration still needs exactly
+ * one all-reduce (SURVEY.md 8e lists the 7 (window - 1) pose floats as part of the slab).  n_floats = 0 removes it. */
+int nsk_grad_extra(nsk_ctx* ctx, float* d_buf, size_t n_floats);
 /* nsk_grad_pack + ncclAllReduce(sum, fp32) on the context's stream + nsk_grad_unpack; comm is an ncclComm_t (RCCL). */
 int nsk_allreduce_grads(nsk_ctx* ctx, void* nccl_comm);
 
@@ -318,6 +351,18 @@ int nsk_last_call_stats(nsk_ctx* ctx, double* alg_bytes, double* alg_flops, int*
  * nsk_profile_begin and nsk_profile_end; _end synchronises and writes "name launches total_ms\n" lines. */
 int nsk_profile_begin(nsk_ctx* ctx);
 int nsk_profile_end(nsk_ctx* ctx, char* buf, size_t buf_bytes);
+
+/* ---- test aids (tests/test_gpu_relu.py, tools/relu_flips.py; never on the product path) ------------------------- */
+/* A ReLU's derivative jumps at zero, so what a gradient test can demand depends on which side of every kink the forward stood.
+ * nsk_debug_relu_bits: the "input > 0" bits the forward of the last nsk_map_step / nsk_track_step / nsk_render_backward saved for decoder
+ * `which` (1 middle, 2 fine, 3 colour; reference src/models/MLP.cpp:92,98 torch::relu), by SAMPLE (ray * S + s): h_bits[M][5][32] bytes.
+ * nsk_debug_preact: the ReLU inputs themselves ([M][5][32] floats, device), recomputed over the same samples by the forward body of the
+ * current matmul mode (N, rays = those of the last step). */
+int nsk_debug_relu_bits(nsk_ctx* ctx, int which, int M, uint8_t* h_bits);
+/* nsk_debug_fetch: a per-sample array of the last step's workspace, to the host: what = 0..2 the occupancy output of decoder 0..2 [M] (their sum is
+ * the sigma whose relu the compositing takes, include/torchlib/utils.h:160), 3 the colour decoder's output [M][4], 4 d loss / d raw [M][4], 5 z [M]. */
+int nsk_debug_fetch(nsk_ctx* ctx, int what, int M, float* h_out);
+int nsk_debug_preact(nsk_ctx* ctx, int which, int N, const float* d_rays_o, const float* d_rays_d, float* d_preact);
 
 #ifdef __cplusplus
 }

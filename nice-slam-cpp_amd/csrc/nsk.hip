@@ -461,6 +461,61 @@ __global__ __launch_bounds__(256) void k_pose_step(int n, const int* pi, const i
     }
 }
 
+// The pose kernels of a whole window in ONE launch (bundle adjustment, reference src/Mapper.cpp:305-329,467-489): block f reduces the ray
+// gradients of frame f's rays [first, first + count) of the batch to d loss / d c2w, chains through quad2rotation to the 7-vector
+// and either steps the pose (adam = 1: k_pose_step's arithmetic, frame by frame) or only stores the gradient (adam = 0: N > 1, the
+// gradients of all frames are summed over the ranks first, then nsk_adam_vector steps every pose at once).  Inactive frames (not optimised,
+// or no ray of theirs in this shard) get a zero gradient.  One more block counts the shard's kept rays into g_out[8 * nframes + 1].
+struct PoseFrames { int first[NSK_MAX_POSE_FRAMES], count[NSK_MAX_POSE_FRAMES]; unsigned char active[NSK_MAX_POSE_FRAMES]; };
+__global__ __launch_bounds__(256) void k_pose_multi(PoseFrames F, int nframes, const int* pi, const int* pj, float fx, float fy, float cx, float cy, int mode,
+                                                    const float* g_ro, const float* g_rd, float* cams, float* ms, float* vs, float step_size, float bc2s,
+                                                    float b1, float b2, float eps, int adam, float* g_out, const uint8_t* keep, int n_keep)
+{
+    __shared__ float sh[4][12];
+    __shared__ float g_c2w[12];
+    const int f = blockIdx.x;
+    if (f == nframes) {                                  // the count of the rays that take part (keep == nullptr: all of them)
+        float cnt = 0.f;
+        for (int r = threadIdx.x; r < n_keep; r += 256) cnt += (!keep || keep[r]) ? 1.f : 0.f;
+        cnt = wave_sum(cnt);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][0] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0 && g_out) g_out[8 * nframes + 1] = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
+        return;
+    }
+    const int n = F.active[f] ? F.count[f] : 0, r0 = F.first[f];
+    float acc[12];
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int r = r0 + threadIdx.x; r < r0 + n; r += 256) {
+        float i = (float)pi[r], j = (float)pj[r];
+        float dir[3] = {(i - cx) / fx, (mode & 1) ? (i - cy) / fy : -(j - cy) / fy, -1.f};
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) acc[4 * a + b] += g_rd[3 * r + a] * dir[b];
+            acc[4 * a + 3] += g_ro[3 * r + a];
+        }
+    }
+    for (int k = 0; k < 12; ++k) { float s = wave_sum(acc[k]); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = s; }
+    __syncthreads();
+    if (threadIdx.x < 12) g_c2w[threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* cam = cams + 8 * f;
+        float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (n > 0) camera_matrix_backward(cam, g_c2w, g);
+        if (g_out) for (int k = 0; k < 8; ++k) g_out[8 * f + k] = g[k];
+        if (adam && F.active[f]) {
+            float* m = ms + 8 * f; float* v = vs + 8 * f;
+            for (int k = 0; k < 7; ++k) {              // k_adam_scalar's update
+                float gg = g[k];
+                float mm = b1 * m[k] + (1.f - b1) * gg;
+                float vv = b2 * v[k] + (1.f - b2) * gg * gg;
+                cam[k] -= step_size * (mm / (sqrtf(vv) / bc2s + eps));
+                m[k] = mm; v[k] = vv;
+            }
+        }
+    }
+}
+
 __global__ void k_inside_filter(RParams R, int N, const float* ro, const float* rd, const float* gt, uint8_t* keep)
 {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -736,7 +791,8 @@ struct nsk_ctx {
     struct CapVec { int n; float* p; const float* g; float* m; float* v; float lr, b1, b2, eps; int step; hipGraphNode_t node; float ss, bc2s; };
     std::vector<CapVec> cap_vecs;               // nsk_adam_vector launches seen during the current capture
     int cap_rollback[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
-    struct GraphRec { bool stale = false; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t adam_node = nullptr; bool has_adam = false; CapAdam adam; std::vector<CapVec> vecs; };
+    int ws_flip = 0;                            // parity of the swaps between the workspace's two sampling-output sets (forward_core): a graph records the set that was primary at capture
+    struct GraphRec { bool stale = false; int flip = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipGraphNode_t adam_node = nullptr; bool has_adam = false; CapAdam adam; std::vector<CapVec> vecs; };
     std::vector<GraphRec> graphs;
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     bool deterministic = false;             // debug: bit-reproducible gradients (see nsk_set_tuning in include/nsk.h)
@@ -749,15 +805,19 @@ struct nsk_ctx {
     int tune_frozen_mid_pct = 100;          // the middle decoder's frozen tile against the fine one's, in percent (its level has 8x the samples per voxel: more same-line atomics)
     int tune_no_frozen_kernel = 0;          // 1: launches without a trainable role also go through k_decode_bwd_multi (experiments, tests)
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
+    // nsk_set_depth_max_batch: the batch whose max(gt_depth) the sampling uses when gt_depth_max < 0 (a ray shard of a larger batch: N > 1)
+    struct DMax { const float* gt = nullptr; const uint8_t* keep = nullptr; int n = 0; } dmax;
+    float* xextra = nullptr; size_t xextra_n = 0;      // nsk_grad_extra: a caller-owned vector that travels with the packed exchange
     int sort_mode = -1;                     // -1 automatic (sort_pays), 0 never, 1 always (nsk_set_sort_mode; tests)
     bool sorted = false;                    // the current step's decoder launches walk the samples in cell-sorted order (ws.perm)
     // nsk_map_prepare: the sampling (+ cell sort) of the NEXT batch rides in the launches of the current step (composite + sample, backward + scan,
     // Adam + place): `req` is a registered batch nothing has been launched for yet, `prep` the batch whose outputs sit (or are being built) in the
     // workspace's second set; done: bit 0 sampled, 1 offsets scanned, 2 placed
     struct Prep { bool valid = false; int stage = 0, N = 0, S = 0; const float* ro = nullptr; const float* rd = nullptr; const float* gt = nullptr;
-                  float gtmax = 0.f; const uint8_t* mask = nullptr; bool sorted = false; int done = 0; RParams R; } prep, req;
+                  float gtmax = 0.f; const uint8_t* mask = nullptr; bool sorted = false; int done = 0; RParams R; DMax dmax; } prep, req;
     int tune_no_piggyback = 0;              // 1: a prepared batch is sampled by launches of its own at the start of its step (experiments, tests)
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
+    int dbg_M = 0, dbg_S = 0;               // sample count / samples per ray of the last forward_core (nsk_debug_relu_bits, nsk_debug_preact)
     int matmul_mode = 2;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split, 2 fp16 2-piece split (nsk_bf16.h)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
     // optional per-kernel timing with HIP events on the context's stream (nsk_profile_begin / _end)
@@ -872,6 +932,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8, 2>, 160 * 1024));
     CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024 - 256)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));      // (<false>, frozen: the scan role keeps a few words of static LDS)
     CHK(set_lds(k_decode_bwd_frozen<false>, 160 * 1024 - 256));
+    CHK(set_lds(k_decode_fwd_dump<0>, 160 * 1024)); CHK(set_lds(k_decode_fwd_dump<1>, 160 * 1024)); CHK(set_lds(k_decode_fwd_dump<2>, 160 * 1024));
     *out = c;
     return 0;
 }
@@ -1676,19 +1737,20 @@ static PlaceArgs place_args(int M, const int* skey, const int* srank, const int*
     return A;
 }
 // the batch maximum of gt_depth has to come from a launch of its own (k_sample's waves take it themselves for smaller batches)
-static bool needs_depth_max(const float* gt, float gtmax, int N) { return gt && gtmax < 0.f && N > 8192; }
+static bool needs_depth_max(const float* gt, float gtmax, int N, const nsk_ctx::DMax& dm) { return gt && gtmax < 0.f && (N > 8192 || dm.n > 0); }
 
 // sampling (+ cell sort) of one batch into the given output set by launches of its own; `done`: stages that have already run (nsk_ctx::Prep)
 static int launch_sampling(nsk_ctx* c, const RParams& R, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax,
-                           const uint8_t* mask, bool sorted, float* z, int* skey, int* srank, int* offs, int* perm, int done = 0)
+                           const uint8_t* mask, bool sorted, float* z, int* skey, int* srank, int* offs, int* perm, const nsk_ctx::DMax& dm, int done = 0)
 {
     const int M = N * S;
     hipStream_t st = c->stream;
     if (!(done & 1)) {
         const float* gmax_dev = nullptr;
-        if (needs_depth_max(gt, gtmax, N)) {
+        if (needs_depth_max(gt, gtmax, N, dm)) {
             ProfScope ps(c, "depth_max");
-            k_depth_max<<<1, 1024, 0, st>>>(N, gt, mask, c->scal);
+            if (dm.n > 0) k_depth_max<<<1, 1024, 0, st>>>(dm.n, dm.gt, dm.keep, c->scal);      // the maximum of the batch this call's rays are a shard of
+            else k_depth_max<<<1, 1024, 0, st>>>(N, gt, mask, c->scal);
             gmax_dev = c->scal;
         }
         ProfScope ps(c, "sample");
@@ -1713,7 +1775,7 @@ static int prep_finish(nsk_ctx* c)
     const int all = P.sorted ? 7 : 1;
     if ((P.done & all) == all) return 0;
     Workspace& w = c->ws;
-    CHK(launch_sampling(c, P.R, P.stage, P.N, P.S, P.ro, P.rd, P.gt, P.gtmax, P.mask, P.sorted, w.z_alt, w.skey_alt, w.srank_alt, w.offs_alt, w.perm_alt, P.done));
+    CHK(launch_sampling(c, P.R, P.stage, P.N, P.S, P.ro, P.rd, P.gt, P.gtmax, P.mask, P.sorted, w.z_alt, w.skey_alt, w.srank_alt, w.offs_alt, w.perm_alt, P.dmax, P.done));
     P.done = all;
     return 0;
 }
@@ -1735,24 +1797,27 @@ static int forward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, co
     const uint8_t* mask = save_masks ? c->ray_mask : nullptr;      // (only the steps that form a loss honour it; a plain render shows every ray)
     auto is_this_batch = [&](const nsk_ctx::Prep& X) {
         return X.valid && save_masks && !c->capturing && X.stage == stage && X.N == N && X.S == S && X.ro == ro && X.rd == rd && X.gt == gt && X.gtmax == gtmax &&
-               X.mask == mask && X.sorted == sorted && memcmp(&X.R, &c->R, sizeof(RParams)) == 0;
+               X.mask == mask && X.sorted == sorted && memcmp(&X.R, &c->R, sizeof(RParams)) == 0 &&
+               X.dmax.gt == c->dmax.gt && X.dmax.keep == c->dmax.keep && X.dmax.n == c->dmax.n;
     };
     nsk_ctx::Prep& P = c->prep;
-    CHK(prep_finish(c));                                    // (also when the set is for another batch: the sampling below needs the cell histogram)
+    if (!c->capturing) CHK(prep_finish(c));                 // (also when the set is for another batch: the sampling below needs the cell histogram; nsk_graph_begin has settled it before a capture)
     if (is_this_batch(P)) {
         // this batch was sampled during the previous step (nsk_map_prepare): take its outputs
         Workspace& w = c->ws;
         std::swap(w.z, w.z_alt); std::swap(w.perm, w.perm_alt); std::swap(w.skey, w.skey_alt); std::swap(w.srank, w.srank_alt);
         std::swap(w.offs, w.offs_alt);                      // (both sets are kept at the same capacities: ensure_alt)
+        c->ws_flip ^= 1;
         P.valid = false;
         c->sorted = sorted;
     } else {
         if (is_this_batch(c->req)) c->req.valid = false;    // registered, but no step came by to carry its sampling: sampled here like any other batch
         c->sorted = sorted;
         if (sorted) CHK(ensure_hist(c, stage_bins(c, stage)));
-        CHK(launch_sampling(c, c->R, stage, N, S, ro, rd, gt, gtmax, mask, sorted, c->ws.z, c->ws.skey, c->ws.srank, c->ws.offs, c->ws.perm));
+        CHK(launch_sampling(c, c->R, stage, N, S, ro, rd, gt, gtmax, mask, sorted, c->ws.z, c->ws.skey, c->ws.srank, c->ws.offs, c->ws.perm, c->dmax));
     }
     CHK(launch_decode_fwd_stage(c, stage, M, S, ro, rd, save_masks));
+    c->dbg_M = M; c->dbg_S = S;
     return 0;
 }
 
@@ -1981,7 +2046,7 @@ extern "C" int nsk_map_prepare(nsk_ctx* c, int stage, int N, const float* ro, co
     if (sorted) CHK(ensure_hist(c, stage_bins(c, stage)));
     CHK(ensure_alt(c, sorted));
     nsk_ctx::Prep& P = c->req;
-    P.valid = true; P.stage = stage; P.N = N; P.S = S; P.ro = ro; P.rd = rd; P.gt = gt; P.gtmax = gtmax; P.mask = c->ray_mask; P.sorted = sorted; P.done = 0; P.R = c->R;
+    P.valid = true; P.stage = stage; P.N = N; P.S = S; P.ro = ro; P.rd = rd; P.gt = gt; P.gtmax = gtmax; P.mask = c->ray_mask; P.sorted = sorted; P.done = 0; P.R = c->R; P.dmax = c->dmax;
     return 0;
 }
 
@@ -1996,7 +2061,7 @@ static int prep_promote(nsk_ctx* c, bool* ride)
     if (R.sorted) CHK(ensure_hist(c, stage_bins(c, R.stage)));
     CHK(ensure_alt(c, R.sorted));
     c->prep = R; c->prep.done = 0; c->req.valid = false;
-    *ride = !c->tune_no_piggyback && !needs_depth_max(R.gt, R.gtmax, R.N);
+    *ride = !c->tune_no_piggyback && !needs_depth_max(R.gt, R.gtmax, R.N, R.dmax);
     return 0;
 }
 
@@ -2123,6 +2188,63 @@ static void invert4(const float* m, float* inv)          // Gauss-Jordan with pa
         for (int r = 0; r < 4; ++r) if (r != c) { double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
     }
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) inv[4 * i + j] = (float)a[i][4 + j];
+}
+
+// ---- test aids: what the last step's forward decided at every ReLU, and the numbers it decided on ----------------------------------
+// (read-only views of the workspace; nothing in the product path calls them.  tests/test_gpu_relu.py, tools/relu_flips.py)
+extern "C" int nsk_debug_relu_bits(nsk_ctx* c, int which, int M, uint8_t* h_bits /*[M][5][32] by sample*/)
+{
+    if (!c || !h_bits) return fail("nsk_debug_relu_bits: null argument");
+    if (which < 1 || which > 3) return fail("nsk_debug_relu_bits: decoder 1..3");
+    if (M < 1 || M != c->dbg_M || M > c->ws.capM) return fail("nsk_debug_relu_bits: M = %d is not the last step's sample count (%d)", M, c->dbg_M);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> mk((size_t)M * 4);
+    std::vector<int> perm;
+    HIPCHK(hipMemcpy(mk.data(), c->ws.masks[which], mk.size() * 8, hipMemcpyDeviceToHost));
+    if (c->sorted) { perm.resize(M); HIPCHK(hipMemcpy(perm.data(), c->ws.perm, (size_t)M * 4, hipMemcpyDeviceToHost)); }
+    for (int slot = 0; slot < M; ++slot) {
+        const int m = c->sorted ? perm[slot] : slot;
+        if (m < 0 || m >= M) return fail("nsk_debug_relu_bits: perm[%d] = %d out of range", slot, m);
+        uint8_t* row = h_bits + (size_t)m * 160;
+        for (int g = 0; g < 4; ++g) {
+            const unsigned long long w = mk[(size_t)slot * 4 + g];
+            for (int l = 0; l < 5; ++l)
+                for (int r = 0; r < 2; ++r)
+                    for (int i = 0; i < 4; ++i) row[32 * l + 16 * r + 4 * g + i] = (uint8_t)((w >> (8 * l + 4 * r + i)) & 1ull);
+        }
+    }
+    return 0;
+}
+// per-sample arrays of the last step's workspace, by sample: what = 0..2 occupancy of decoder 0..2 [M], 3 colour decoder output [M][4], 4 g_raw [M][4], 5 z [M]
+extern "C" int nsk_debug_fetch(nsk_ctx* c, int what, int M, float* h_out)
+{
+    if (!c || !h_out) return fail("nsk_debug_fetch: null argument");
+    if (M < 1 || M != c->dbg_M || M > c->ws.capM) return fail("nsk_debug_fetch: M = %d is not the last step's sample count (%d)", M, c->dbg_M);
+    const float* src = what >= 0 && what <= 2 ? c->ws.occ[what] : (what == 3 ? c->ws.rgb4 : (what == 4 ? c->ws.g_raw : (what == 5 ? c->ws.z : nullptr)));
+    if (!src) return fail("nsk_debug_fetch: what = 0..5");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(h_out, src, (size_t)M * ((what == 3 || what == 4) ? 16 : 4), hipMemcpyDeviceToHost));
+    return 0;
+}
+// the ReLU inputs of decoder `which` over the samples of the last step (same rays), by the forward body of the current matmul mode
+extern "C" int nsk_debug_preact(nsk_ctx* c, int which, int N, const float* ro, const float* rd, float* d_out /*[M][5][32] device*/)
+{
+    if (!c || !ro || !rd || !d_out) return fail("nsk_debug_preact: null argument");
+    if (which < 1 || which > 3) return fail("nsk_debug_preact: decoder 1..3");
+    const int S = c->dbg_S, M = c->dbg_M;
+    if (S < 1 || N * S != M) return fail("nsk_debug_preact: N = %d does not match the last step (%d samples, %d per ray)", N, M, S);
+    HIPCHK(hipSetDevice(c->device));
+    DecArgs A;
+    fill_args(c, A, which, M, S, ro, rd, nullptr);
+    A.dump = d_out;
+    const int grid = std::max(1, std::min(((M + 15) / 16 + 7) / 8, c->num_cu));
+    if (c->matmul_mode == 0) k_decode_fwd_dump<0><<<grid, 512, fwd_img_floats(which) * 4, c->stream>>>(A, which);
+    else if (c->matmul_mode == 1) k_decode_fwd_dump<1><<<grid, 512, (size_t)c->dec[which].fimg16_f * 4, c->stream>>>(A, which);
+    else k_decode_fwd_dump<2><<<grid, 512, (size_t)c->dec[which].fimg16_f * 4, c->stream>>>(A, which);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 #ifdef NSK_EXPERIMENT
@@ -2300,6 +2422,45 @@ extern "C" int nsk_pose_step(nsk_ctx* c, int n, const int32_t* pi, const int32_t
     HIPCHK(hipGetLastError());
     return 0;
 }
+extern "C" int nsk_pose_step_multi(nsk_ctx* c, int nframes, const int* h_first, const int* h_count, const uint8_t* h_active, const int32_t* pi, const int32_t* pj,
+                                   float fx, float fy, float cx, float cy, int mode, const float* g_ro, const float* g_rd, float* d_cams, float* d_m, float* d_v,
+                                   float lr, float b1, float b2, float eps, int step, float* d_g_cams, const uint8_t* d_keep, int n_keep)
+{
+    if (!c || !h_first || !h_count || !h_active || !pi || !pj || !g_ro || !g_rd || !d_cams) return fail("nsk_pose_step_multi: null argument");
+    if (nframes < 1 || nframes > NSK_MAX_POSE_FRAMES) return fail("nsk_pose_step_multi: 1 <= nframes <= %d (got %d)", NSK_MAX_POSE_FRAMES, nframes);
+    if (step < 0 || (step > 0 && (!d_m || !d_v))) return fail("nsk_pose_step_multi: step >= 1 needs the Adam moments (step 0 = gradients only)");
+    if (step == 0 && !d_g_cams) return fail("nsk_pose_step_multi: step 0 (gradients only) needs d_g_cams");
+    HIPCHK(hipSetDevice(c->device));
+    PoseFrames F; memset(&F, 0, sizeof(F));
+    for (int f = 0; f < nframes; ++f) {
+        if (h_first[f] < 0 || h_count[f] < 0) return fail("nsk_pose_step_multi: frame %d has a negative ray range", f);
+        F.first[f] = h_first[f]; F.count[f] = h_count[f]; F.active[f] = h_active[f] ? 1 : 0;
+    }
+    intr(mode, fx, fy, cx, cy);
+    float ss = 0.f, bc2s = 1.f;
+    if (step > 0) adam_consts(lr, b1, b2, step, ss, bc2s);
+    const int count_block = (d_g_cams && n_keep > 0) ? 1 : 0;
+    ProfScope ps(c, "pose_multi");
+    k_pose_multi<<<nframes + count_block, 256, 0, c->stream>>>(F, nframes, pi, pj, fx, fy, cx, cy, mode, g_ro, g_rd, d_cams, d_m, d_v, ss, bc2s, b1, b2, eps,
+                                                             step > 0 ? 1 : 0, d_g_cams, d_keep, n_keep);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int nsk_set_depth_max_batch(nsk_ctx* c, const float* d_gt_depth, const uint8_t* d_keep, int n)
+{
+    if (!c) return fail("null ctx");
+    if (n < 0 || (n > 0 && !d_gt_depth)) return fail("nsk_set_depth_max_batch: bad argument");
+    c->dmax.gt = n > 0 ? d_gt_depth : nullptr; c->dmax.keep = n > 0 ? d_keep : nullptr; c->dmax.n = n;
+    return 0;
+}
+extern "C" int nsk_grad_extra(nsk_ctx* c, float* d_buf, size_t n_floats)
+{
+    if (!c) return fail("null ctx");
+    if (n_floats % 4 != 0 || (n_floats > 0 && !d_buf)) return fail("nsk_grad_extra: a device buffer of a multiple of 4 floats (or 0 floats to remove it)");
+    if (((uintptr_t)d_buf & 15) != 0) return fail("nsk_grad_extra: the buffer must be 16-byte aligned");
+    c->xextra = n_floats ? d_buf : nullptr; c->xextra_n = n_floats;
+    return 0;
+}
 extern "C" int nsk_prepare_rays(nsk_ctx* c, int nframes, const nsk_frame_rays* fr, int per, int H0, int H1, int W0, int W1, int H, int W,
                                 float fx, float fy, float cx, float cy, int mode, int32_t* pi, int32_t* pj, float* gd, float* gc,
                                 float* ro, float* rd, uint8_t* keep)
@@ -2430,6 +2591,10 @@ extern "C" int nsk_graph_begin(nsk_ctx* c)
     if (c->capturing) return fail("nsk_graph_begin: a capture is already open");
     HIPCHK(hipSetDevice(c->device));
     CHK(flush_pending(c));
+    // A batch registered with nsk_map_prepare is settled BEFORE the capture opens: whatever of its sampling / cell sort has not run yet runs now,
+    // eagerly (inside the capture forward_core's prep_finish would have recorded those launches into the graph instead of running them, and the
+    // batch's own step would then have swapped in buffers nobody filled); the batch stays prepared for its own eager step.
+    CHK(prep_finish(c));
     HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     c->capturing = true;
     c->cap_adams.clear(); c->cap_vecs.clear();
@@ -2469,6 +2634,7 @@ extern "C" int nsk_graph_end(nsk_ctx* c, int* graph_id)
         for (auto& V : R.vecs) if (!V.node) { hipGraphDestroy(R.graph); return fail("nsk_graph_end: an nsk_adam_vector node was not found in the captured graph"); }
     }
     HIPCHK(hipGraphInstantiate(&R.exec, R.graph, nullptr, nullptr, 0));
+    R.flip = c->ws_flip;
     c->graphs.push_back(R);
     *graph_id = (int)c->graphs.size() - 1;
     return 0;
@@ -2481,6 +2647,11 @@ extern "C" int nsk_graph_launch(nsk_ctx* c, int id)
     if (!c->graphs[id].exec) return fail("nsk_graph_launch: graph %d was destroyed", id);
     HIPCHK(hipSetDevice(c->device));
     nsk_ctx::GraphRec& R = c->graphs[id];
+    // A prepared batch (nsk_map_prepare) and a replay share the cell histogram and, after an odd number of set swaps since the capture, the very
+    // buffers the graph writes: finish the batch's pending stages first (a histogram still holding its counts would be added onto by the
+    // replayed sampling), and where the graph's recorded set is the one the batch lives in, drop the batch -- its own step samples it again.
+    CHK(prep_finish(c));
+    if (c->prep.valid && R.flip != c->ws_flip) CHK(prep_drop(c));
     if (R.has_adam) {                            // this replay is one more Adam step for the groups the graph updates
         AdamArgs& A = R.adam.args;
         int stepped[NSK_NUM_GROUPS] = {0, 0, 0, 0, 0, 0};
@@ -2578,6 +2749,7 @@ static int pack_layout(nsk_ctx* c, size_t* total)
         if (c->xdecs[w]) n += (size_t)((c->dec[w].n + 3) & ~3);
     }
     n += 4;
+    n += c->xextra_n;
     *total = n;
     return 0;
 }
@@ -2612,6 +2784,7 @@ static int pack_move(nsk_ctx* c, bool gather)
         add(nullptr, (size_t)((c->dec[w].n + 3) & ~3) / 4, c->slab + c->dec[w].g_off, w);
     }
     add(nullptr, 1, c->slab + c->slab_n - 4);                 // loss scalars
+    if (c->xextra_n) add(nullptr, c->xextra_n / 4, c->xextra); // the caller's vector (nsk_grad_extra: pose gradients of a bundle-adjustment step)
     if (blocks > 0) k_xchg_multi<<<blocks, 256, 0, c->stream>>>(A);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2625,7 +2798,7 @@ extern "C" int nsk_grad_pack(nsk_ctx* c, float** p, size_t* n)
     CHK(pack_layout(c, &total));
     bool any_mask = false;
     for (int l = 0; l < 4; ++l) any_mask = any_mask || (c->xlevels[l] && c->grid[l].mask);
-    if (!any_mask) {                                   // nothing to compact: exchange the slab in place (no copies); unpack is then a no-op
+    if (!any_mask && !c->xextra_n) {                   // nothing to compact: exchange the slab in place (no copies); unpack is then a no-op
         CHK(flush_pending(c));
         c->xbuf_n = 0; c->x_identity = true;
         *p = c->slab; *n = c->slab_n;

@@ -97,8 +97,8 @@ struct FwdSchedB {
 };
 
 // MLP::forward (reference src/models/MLP.cpp:76-102) on the bf16 matrix cores; same results as mlp_forward to fp32 rounding
-template <int CQ>
-__device__ __forceinline__ void mlp_forward_bf16(const bf8* __restrict__ img, const float* __restrict__ imgf, int lane, Act<CQ>& A)
+template <int CQ, bool DUMP = false>
+__device__ __forceinline__ void mlp_forward_bf16(const bf8* __restrict__ img, const float* __restrict__ imgf, int lane, Act<CQ>& A, float* dump = nullptr)
 {
     typedef MlpFwdImgB<CQ> I;
     constexpr FwdSchedB<CQ> S{};
@@ -119,6 +119,7 @@ __device__ __forceinline__ void mlp_forward_bf16(const bf8* __restrict__ img, co
         __builtin_amdgcn_sched_barrier(0);
         mac_block(ring[s & 1][0], ring[s & 1][1], X[S.xs[s]], acc);
         if (S.bnd[s] == 1) {
+            if constexpr (DUMP) dump_preact(dump, S.lay[s], g, acc);
             mask |= (unsigned long long)relu_mask(acc) << (8 * S.lay[s]);
             f4 bc[2]; load_bias(imgf + I::P_BC + 32 * S.lay[s], g, bc); acc[0] += bc[0]; acc[1] += bc[1];
         } else if (S.bnd[s] == 2) {
@@ -132,8 +133,8 @@ __device__ __forceinline__ void mlp_forward_bf16(const bf8* __restrict__ img, co
 
 // the same chain on fp16 pieces (matmul mode 2): three MFMAs per K=32 block and row tile instead of six, two accumulator sets
 // (accH: Wh x_h from the bias on; accL: the two cross products, in units of 1/2048) that meet before every ReLU and block output
-template <int CQ>
-__device__ __forceinline__ void mlp_forward_f16(const h8* __restrict__ img, const float* __restrict__ imgf, int lane, Act<CQ>& A)
+template <int CQ, bool DUMP = false>
+__device__ __forceinline__ void mlp_forward_f16(const h8* __restrict__ img, const float* __restrict__ imgf, int lane, Act<CQ>& A, float* dump = nullptr)
 {
     typedef MlpFwdImgB<CQ, 2> I;
     constexpr FwdSchedB<CQ> S{};
@@ -159,6 +160,7 @@ __device__ __forceinline__ void mlp_forward_f16(const h8* __restrict__ img, cons
             accL[0] = (f4)(0.f); accL[1] = (f4)(0.f);
         }
         if (S.bnd[s] == 1) {
+            if constexpr (DUMP) dump_preact(dump, S.lay[s], g, acc);
             mask |= (unsigned long long)relu_mask(acc) << (8 * S.lay[s]);
             f4 bc[2]; load_bias(imgf + I::P_BC + 32 * S.lay[s], g, bc); acc[0] += bc[0]; acc[1] += bc[1];
         } else if (S.bnd[s] == 2) {
@@ -171,7 +173,7 @@ __device__ __forceinline__ void mlp_forward_f16(const h8* __restrict__ img, cons
 }
 
 // K2 (bf16-split form): same contract as decode_fwd_body for the MLP decoders (WHICH = 1, 2, 3)
-template <int WHICH, int NW = 8, int NP = 3>
+template <int WHICH, int NW = 8, int NP = 3, bool DUMP = false>
 __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, int nb)
 {
     constexpr int CQ = WHICH == 2 ? 4 : 2;
@@ -221,8 +223,10 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
             tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
             tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
         }
-        if constexpr (NP == 2) mlp_forward_f16<CQ>(reinterpret_cast<const h8*>(smem), imgf, lane, C);
-        else mlp_forward_bf16<CQ>(img, imgf, lane, C);
+        float* dump = nullptr;
+        if constexpr (DUMP) dump = slot < A.M ? A.dump + (size_t)m_cur * 160 : nullptr;
+        if constexpr (NP == 2) mlp_forward_f16<CQ, DUMP>(reinterpret_cast<const h8*>(smem), imgf, lane, C, dump);
+        else mlp_forward_bf16<CQ, DUMP>(img, imgf, lane, C, dump);
         float out[OD];
         mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);
         if (slot < A.M) {
@@ -248,5 +252,26 @@ __global__ __launch_bounds__(64 * NW) void k_decode_fwd_multi_bf16(MultiArgs MA)
     case 1: decode_fwd_bf16_body<1, NW, NP>(MA.a[r], bid, nb); break;
     case 2: decode_fwd_bf16_body<2, NW, NP>(MA.a[r], bid, nb); break;
     default: decode_fwd_bf16_body<3, NW, NP>(MA.a[r], bid, nb); break;
+    }
+}
+
+// test aid (nsk_debug_preact): one MLP decoder's forward over the samples of the last step, the same body as the step's launch with the
+// ReLU inputs written out.  MODE = matmul mode (0 fp32 MFMA, 1 three bf16 pieces, 2 two fp16 pieces)
+template <int MODE>
+__global__ __launch_bounds__(512) void k_decode_fwd_dump(DecArgs A, int which)
+{
+    if constexpr (MODE == 0) {
+        switch (which) {
+        case 1: decode_fwd_body<1, 8, true>(A, blockIdx.x, gridDim.x); break;
+        case 2: decode_fwd_body<2, 8, true>(A, blockIdx.x, gridDim.x); break;
+        default: decode_fwd_body<3, 8, true>(A, blockIdx.x, gridDim.x); break;
+        }
+    } else {
+        constexpr int NP = MODE == 2 ? 2 : 3;
+        switch (which) {
+        case 1: decode_fwd_bf16_body<1, 8, NP, true>(A, blockIdx.x, gridDim.x); break;
+        case 2: decode_fwd_bf16_body<2, 8, NP, true>(A, blockIdx.x, gridDim.x); break;
+        default: decode_fwd_bf16_body<3, 8, NP, true>(A, blockIdx.x, gridDim.x); break;
+        }
     }
 }

@@ -51,11 +51,15 @@ __device__ __forceinline__ void copy_image_to_lds(f4* __restrict__ dst, const f4
 
 // ------------------------------------------------------------------------------------------------------
 // scalar helpers that spell out the operation sequence of the reference's libtorch ops for the sampling geometry (it feeds sin(25*x) and
-// ReLU kinks).  They fix the ORDER of operations; they are not contraction barriers: HIP's __fmul_rn / __fadd_rn are plain operators and
-// hipcc may fuse a product into the following sum (as the CPU path's BLAS does inside p @ B).  Where bit-equality between two kernels is
-// required (camera_matrix, nsk.hip) the function carries #pragma clang fp contract(off).
+// ReLU kinks): every libtorch tensor op rounds on its own, so `rays_o + rays_d * z` (src/Renderer.cpp:121) is a rounded product and a
+// rounded sum.  hipcc contracts a * b + c into an FMA by default, across statements and inlined calls, and decides so per instantiation:
+// until round 4 the SAME source gave different p = o + d z in different kernels (two instantiations of one forward body disagreed on
+// ~130 of 38 M ReLU branches at K3, as many as either disagreed with the CPU oracle: tools/relu_flips.py).  mul_rn
+// therefore hides its product from the optimiser behind an empty asm (no instruction, the value just becomes opaque): a product formed by
+// mul_rn is never fused into a following add.  Where the reference itself fuses -- torch::matmul's K = 3 dot product in GaussianFFT is an
+// FMA chain on the CPU (tests/test_oracle.py::test_aten_matmul_k3_is_an_fma_chain) -- the code says so with an explicit fmaf (embed()).
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float mul_rn(float a, float b) { float r = a * b; asm("" : "+v"(r)); return r; }
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
@@ -639,6 +643,14 @@ __device__ __forceinline__ uint32_t relu_mask(f4 (&a)[2])
     return m;
 }
 
+// test aid (nsk_debug_preact): the ReLU inputs of layer l as the chain holds them, row = sample, [5][32] floats
+__device__ __forceinline__ void dump_preact(float* __restrict__ row, int l, int g, const f4 (&acc)[2])
+{
+    if (!row) return;
+    *reinterpret_cast<f4*>(row + 32 * l + 4 * g) = acc[0];
+    *reinterpret_cast<f4*>(row + 32 * l + 16 + 4 * g) = acc[1];
+}
+
 template <int CQ>
 struct Act {               // activations of one 16-sample tile, D layout
     f4 xe[6];              // sin(pB), k = 16q+4g+i (k>=93: 0)
@@ -680,7 +692,8 @@ __device__ __forceinline__ void embed(const float* __restrict__ Bm /*[3][96]*/, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int k = 16 * q + 4 * g + i;
-            float s = add_rn(add_rn(mul_rn(px, b0[i]), mul_rn(py, b1[i])), mul_rn(pz, b2[i]));
+            // torch::matmul(p, B) (GaussianFFT.cpp:13): the CPU BLAS accumulates the K = 3 products with FMAs in k order
+            float s = __builtin_fmaf(pz, b2[i], __builtin_fmaf(py, b1[i], mul_rn(px, b0[i])));
             float sv, cv = 0.f;
             if (WANT_COS) nsk_sincos(s, sv, cv); else sv = nsk_sin(s);
             xe[q][i] = k < NSK_E ? sv : 0.f;
@@ -690,8 +703,8 @@ __device__ __forceinline__ void embed(const float* __restrict__ Bm /*[3][96]*/, 
 }
 
 // MLP::forward (reference src/models/MLP.cpp:76-102, intended loop D14): fills A.h and A.mask
-template <int CQ>
-__device__ __forceinline__ void mlp_forward(const f4* __restrict__ img, int lane, Act<CQ>& A)
+template <int CQ, bool DUMP = false>
+__device__ __forceinline__ void mlp_forward(const f4* __restrict__ img, int lane, Act<CQ>& A, float* dump = nullptr)
 {
     typedef MlpFwdImg<CQ> I;
     const float* imgf = reinterpret_cast<const float*>(img);
@@ -701,6 +714,7 @@ __device__ __forceinline__ void mlp_forward(const f4* __restrict__ img, int lane
     // block 0
     load_bias(imgf + I::P_B, g, acc);
     gemm<2, 6>(img, I::W0E, lane, A.xe, acc);
+    if constexpr (DUMP) dump_preact(dump, 0, g, acc);
     mask |= (unsigned long long)relu_mask(acc);
     { f4 bc[2]; load_bias(imgf + I::P_BC, g, bc); acc[0] += bc[0]; acc[1] += bc[1]; }
     gemm<2, CQ>(img, I::F0, lane, A.xc, acc);
@@ -714,6 +728,7 @@ __device__ __forceinline__ void mlp_forward(const f4* __restrict__ img, int lane
         } else {
             gemm<2, 2>(img, I::W(l), lane, A.h[l - 1], acc);
         }
+        if constexpr (DUMP) dump_preact(dump, l, g, acc);
         mask |= (unsigned long long)relu_mask(acc) << (8 * l);
         { f4 bc[2]; load_bias(imgf + I::P_BC + 32 * l, g, bc); acc[0] += bc[0]; acc[1] += bc[1]; }
         gemm<2, CQ>(img, I::F(l), lane, A.xc, acc);
@@ -789,6 +804,7 @@ struct DecArgs {
     float* g_rays_o; float* g_rays_d;    // [N][3] accumulated with atomics, or nullptr
     float* g_dec;             // canonical decoder gradient (trainable) or nullptr
     unsigned flags;
+    float* dump;              // test aid (nsk_debug_preact): ReLU inputs [M][5][32] by sample, or nullptr
     int skew;                 // start offset of a workgroup's upper four waves, in units of 1024 cycles (wave_skew)
 };
 
@@ -882,7 +898,7 @@ __device__ __forceinline__ void save_h(f4* __restrict__ hsave, int task, int lan
 
 // bid / nb: this workgroup's index and the number of workgroups working on this decoder (a launch may serve
 // several decoders, each with its own slice of the grid: k_decode_fwd_multi)
-template <int WHICH, int NW = 8>
+template <int WHICH, int NW = 8, bool DUMP = false>
 __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int nb)
 {
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
@@ -929,7 +945,9 @@ __device__ __forceinline__ void decode_fwd_body(const DecArgs& A, int bid, int n
             }
             f4 dummy[6];
             embed<false>(imgf + I::P_BM, g, px, py, pz, C.xe, dummy);
-            mlp_forward<CQ>(smem, lane, C);
+            float* dump = nullptr;
+            if constexpr (DUMP) dump = valid ? A.dump + (size_t)m * 160 : nullptr;
+            mlp_forward<CQ, DUMP>(smem, lane, C, dump);
             float out[OD];
             mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);
             if (valid) {

@@ -7,6 +7,7 @@
 #include "inputs/CoFusionReader.h"
 #include <yaml-cpp/yaml.h>
 #include "Renderer.h"
+#include "nsk_host.h"
 #include <algorithm>
 
 struct KeyFrame {
@@ -32,6 +33,14 @@ class Mapper {
     void set_frustum_mask(const std::string& grid_key, torch::Tensor mask_zyx);     // bool/uint8 [Z,Y,X]; undefined tensor = all
     void set_bound(torch::Tensor bound_3x2);
     void seed(uint64_t s) { rng_seed = s; draw_calls = 0; }
+    // N > 1 (BASELINE configs[3], [4]): every rank draws the window's whole batch (the pixel draw is a counter hash of the seed: identical on
+    // every rank, one small launch), renders the contiguous shard [lo, hi) of it with the batch's max(gt_depth) taken over the whole batch
+    // (nsk_set_depth_max_batch: no collective), and ONE all-reduce per iteration sums the marked voxels' gradients, the colour decoder's, the
+    // loss and -- in bundle-adjustment iterations -- the 8 floats per window frame of pose gradient (nsk_grad_extra); every rank then applies the
+    // same Adam steps to grids, decoder and poses, so the replicas stay bit-identical without a broadcast.  All ranks must call seed() alike.
+    void set_distributed(const nskh::Dist& d) { dist = d; }
+    nskh::Dist dist;
+    float last_kept_rays = 0.f;            // kept rays of the last bundle-adjustment iteration, summed over the ranks (N > 1; the shards must add up to the batch)
     // seed of the d-th pixel draw of this Mapper (d = 1, 2, ...: every keyframe_selection_overlap and every optimize_map call takes the next
     // one, so no two calls draw the same pixels -- the reference draws fresh torch::randint pixels every call, utils.h:19-36)
     static uint64_t draw_seed(uint64_t seed, uint64_t d) { return seed + 0xD1B54A32D192ED03ull * d; }

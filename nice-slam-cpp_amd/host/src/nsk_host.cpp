@@ -4,7 +4,11 @@
 // Each function cites the reference code whose behaviour it reproduces (intended semantics).
 #include <hip/hip_runtime_api.h>
 
+#include <dlfcn.h>
+
 #include <chrono>
+#include <thread>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +50,73 @@ int stage_id(const std::string& s)
     if (s == "fine") return NSK_FINE;
     if (s == "color") return NSK_COLOR;
     throw std::runtime_error("unknown stage '" + s + "'");
+}
+
+// ---- N > 1 ---------------------------------------------------------------------------------------------
+void Dist::shard(int n, int* lo, int* hi) const
+{
+    const int base = n / world, rem = n % world;
+    *lo = rank * base + std::min(rank, rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+static void* rccl_sym(const char* name)
+{
+    static void* h = nullptr;
+    if (!h) { h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); }
+    if (!h) throw std::runtime_error(std::string("cannot load librccl.so: ") + dlerror());
+    void* f = dlsym(h, name);
+    if (!f) throw std::runtime_error(std::string("librccl: symbol not found: ") + name);
+    return f;
+}
+void Dist::allreduce(float* d_buf, size_t n) const
+{
+    if (!on() || n == 0) return;
+    if (hook) { hook(d_buf, n, user); return; }
+    if (!comm) throw std::runtime_error("nskh::Dist: world > 1 needs an RCCL communicator or an exchange hook");
+    typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_t fn = (allreduce_t)rccl_sym("ncclAllReduce");
+    if (fn(d_buf, d_buf, n, 7 /* ncclFloat32 */, 0 /* ncclSum */, comm, (hipStream_t)nsk_stream(ctx())) != 0) throw std::runtime_error("ncclAllReduce failed");
+}
+void Dist::allreduce_grads() const
+{
+    if (!on()) return;
+    if (comm && !hook) { check(nsk_allreduce_grads(ctx(), comm)); return; }
+    float* buf = nullptr; size_t n = 0;
+    check(nsk_grad_pack(ctx(), &buf, &n));
+    allreduce(buf, n);
+    check(nsk_grad_unpack(ctx()));
+}
+void Dist::broadcast0(float* d_buf, size_t n) const
+{
+    if (!on()) return;
+    if (rank != 0 && hipMemsetAsync(d_buf, 0, n * sizeof(float), (hipStream_t)nsk_stream(ctx())) != hipSuccess) throw std::runtime_error("hipMemsetAsync failed");
+    allreduce(d_buf, n);
+}
+void* rccl_comm_from_file(int rank, int world, const std::string& id_file)
+{
+    struct UniqueId { char internal[128]; } id;
+    typedef int (*getid_t)(UniqueId*);
+    typedef int (*init_t)(void**, int, UniqueId, int);
+    std::memset(&id, 0, sizeof(id));
+    if (rank == 0) {
+        if (((getid_t)rccl_sym("ncclGetUniqueId"))(&id) != 0) throw std::runtime_error("ncclGetUniqueId failed");
+        const std::string tmp = id_file + ".tmp";
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(&id, 1, sizeof(id), f) != sizeof(id)) throw std::runtime_error("cannot write " + tmp);
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file);     // atomic: readers never see a partial id
+    } else {
+        for (int tries = 0; ; ++tries) {
+            FILE* f = std::fopen(id_file.c_str(), "rb");
+            if (f) { const size_t got = std::fread(&id, 1, sizeof(id), f); std::fclose(f); if (got == sizeof(id)) break; }
+            if (tries > 6000) throw std::runtime_error("timed out waiting for " + id_file);
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+    }
+    ctx();                                              // the communicator lives on this process's device (NSK_DEVICE)
+    void* comm = nullptr;
+    if (((init_t)rccl_sym("ncclCommInitRank"))(&comm, world, id, rank) != 0 || !comm) throw std::runtime_error("ncclCommInitRank failed");
+    return comm;
 }
 
 DevBuf::~DevBuf() { if (p) hipFree(p); }
@@ -645,6 +716,7 @@ struct Mapper::Dev {
     DevArr<float> poses;                                 // [frames of the window][12] fixed c2w rows (3x4)
     DevArr<float> cams, cam_m, cam_v, cam_g;             // BA: [frames][8] pose 7-vectors, their Adam moments and their last gradients
     DevArr<float> loss;
+    DevArr<float> x_ba, x_plain;                         // N > 1: what travels beside the grids -- BA iterations [frames][8] pose gradients | loss | kept rays | 0 x 6; others loss | 0 x 3
     DevArr<float> kf_ro, kf_rd, kf_gd;                   // the 100 overlap-ranking rays
     DevArr<int32_t> kf_pi, kf_pj;
 };
@@ -800,7 +872,19 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     }
     D.poses.upload(h_pose.data(), h_pose.size());
     D.cams.upload(h_cam.data(), h_cam.size());
-    D.cam_m.zero((size_t)nf * 8); D.cam_v.zero((size_t)nf * 8); D.cam_g.zero((size_t)nf * 8);
+    D.cam_m.zero((size_t)nf * 8); D.cam_v.zero((size_t)nf * 8); D.cam_g.zero((size_t)nf * 8 + 8);
+    // N > 1: this rank's contiguous shard [lo, hi) of the frame-major batch ("rank r takes rays [r N / G, (r + 1) N / G)")
+    const bool sharded = dist.on();
+    int lo = 0, hi = N;
+    if (sharded) dist.shard(N, &lo, &hi);
+    const int Nl = hi - lo;
+    if (sharded) { D.x_ba.zero((size_t)nf * 8 + 8); D.x_plain.zero(4); }
+    std::vector<int> fr_first((size_t)nf), fr_count((size_t)nf);
+    std::vector<uint8_t> fr_active((size_t)nf);
+    for (int i = 0; i < nf; ++i) {                                                             // frame i's rays inside the shard
+        const int a = std::max(lo, i * pixs_per_image), b = std::min(hi, (i + 1) * pixs_per_image);
+        fr_first[i] = a; fr_count[i] = std::max(0, b - a); fr_active[i] = is_ba[i] ? 1 : 0;
+    }
     D.rays.ensure((size_t)N); D.rays2.ensure((size_t)N); D.loss.ensure((size_t)std::max(4, num_joint_iters_));           // one loss slot per iteration
     RayBufs* bufs[2] = {&D.rays, &D.rays2};
     const bool any_ba = BA && std::count(is_ba.begin(), is_ba.end(), 1) > 0;
@@ -846,28 +930,46 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
         if (drawn_upto < joint_iter) { draw_rays(joint_iter, R); drawn_upto = joint_iter; }
         // The next iteration's batch is drawn and registered before this one is optimised, so that its sampling and cell sort ride in this
         // iteration's launches (nsk_map_prepare) -- unless its rays depend on this iteration's result (bundle adjustment moves the poses)
-        if (joint_iter + 1 < num_joint_iters_ && !(any_ba && stage_of(joint_iter + 1) == "color")) {
+        if (!sharded && joint_iter + 1 < num_joint_iters_ && !(any_ba && stage_of(joint_iter + 1) == "color")) {      // (a shard's sampling waits for the batch maximum: nothing to ride)
             RayBufs& Rn = *bufs[(joint_iter + 1) & 1];
             draw_rays(joint_iter + 1, Rn); drawn_upto = joint_iter + 1;
             check(nsk_set_ray_mask(ctx(), Rn.keep.p));
             check(nsk_map_prepare(ctx(), nskh::stage_id(render_stage_of(joint_iter + 1)), N, Rn.ro.p, Rn.rd.p, Rn.gd.p, -1.f, NSK_GRAD_GRIDS | NSK_GRAD_DECODERS));
         }
-        check(nsk_set_ray_mask(ctx(), R.keep.p));
         unsigned flags = NSK_GRAD_GRIDS | NSK_GRAD_DECODERS | (ba_now ? NSK_GRAD_RAYS : 0u);
         const std::string render_stage = render_stage_of(joint_iter);
-        check(nsk_map_step(ctx(), nskh::stage_id(render_stage), N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, stage == "color" ? 1 : 0, flags,
-                           D.loss.p + joint_iter, nullptr, nullptr, nullptr, ba_now ? R.g_ro.p : nullptr, ba_now ? R.g_rd.p : nullptr));      // :430-444
-        check(nsk_set_ray_mask(ctx(), nullptr));
-        check(nsk_adam_step(ctx(), lr, 0.9f, 0.999f, 1e-8f));                                 // :445-446
-        if (ba_now) {                                                                         // pose gradients through the ray generator and quad2rotation + Adam, per frame
-            ++ba_step;
-            for (int i = 0; i < nf; ++i) {
-                if (!is_ba[i]) continue;
-                const size_t o = (size_t)i * pixs_per_image;
-                check(nsk_pose_step(ctx(), pixs_per_image, R.pi.p + o, R.pj.p + o, fx, fy, cx, cy, 0, R.g_ro.p + 3 * o, R.g_rd.p + 3 * o, D.cams.p + 8 * i,
-                                    D.cam_m.p + 8 * i, D.cam_v.p + 8 * i, BA_cam_lr, 0.9f, 0.999f, 1e-8f, ba_step, D.cam_g.p + 8 * i));
-            }
+        if (!sharded) {
+            check(nsk_set_ray_mask(ctx(), R.keep.p));
+            check(nsk_map_step(ctx(), nskh::stage_id(render_stage), N, R.ro.p, R.rd.p, R.gd.p, R.gc.p, -1.f, w_color_loss, stage == "color" ? 1 : 0, flags,
+                               D.loss.p + joint_iter, nullptr, nullptr, nullptr, ba_now ? R.g_ro.p : nullptr, ba_now ? R.g_rd.p : nullptr));      // :430-444
+            check(nsk_set_ray_mask(ctx(), nullptr));
+            check(nsk_adam_step(ctx(), lr, 0.9f, 0.999f, 1e-8f));                             // :445-446
+            if (ba_now)                                                                       // pose gradients through the ray generator and quad2rotation + Adam: every frame of the window in one launch
+                check(nsk_pose_step_multi(ctx(), nf, fr_first.data(), fr_count.data(), fr_active.data(), R.pi.p, R.pj.p, fx, fy, cx, cy, 0, R.g_ro.p, R.g_rd.p,
+                                          D.cams.p, D.cam_m.p, D.cam_v.p, BA_cam_lr, 0.9f, 0.999f, 1e-8f, ++ba_step, D.cam_g.p, nullptr, 0));
+            continue;
         }
+        // ---- N > 1: the shard's step, one exchange, the replicated optimiser steps ------------------------------------------------
+        float* xt = ba_now ? D.x_ba.p : D.x_plain.p;                                          // what travels beside the grids this iteration
+        float* loss_slot = ba_now ? xt + (size_t)nf * 8 : xt;
+        check(nsk_set_depth_max_batch(ctx(), R.gd.p, R.keep.p, N));                           // max(gt_depth) over the WHOLE batch (Renderer.cpp:76,93)
+        check(nsk_set_ray_mask(ctx(), R.keep.p + lo));
+        if (Nl > 0)
+            check(nsk_map_step(ctx(), nskh::stage_id(render_stage), Nl, R.ro.p + 3 * (size_t)lo, R.rd.p + 3 * (size_t)lo, R.gd.p + lo, R.gc.p + 3 * (size_t)lo, -1.f,
+                               w_color_loss, stage == "color" ? 1 : 0, flags, loss_slot, nullptr, nullptr, nullptr,
+                               ba_now ? R.g_ro.p + 3 * (size_t)lo : nullptr, ba_now ? R.g_rd.p + 3 * (size_t)lo : nullptr));
+        check(nsk_set_ray_mask(ctx(), nullptr));
+        check(nsk_set_depth_max_batch(ctx(), nullptr, nullptr, 0));
+        if (ba_now)                                                                           // this shard's part of every frame's pose gradient (no step yet) + its kept-ray count
+            check(nsk_pose_step_multi(ctx(), nf, fr_first.data(), fr_count.data(), fr_active.data(), R.pi.p, R.pj.p, fx, fy, cx, cy, 0, R.g_ro.p, R.g_rd.p,
+                                      D.cams.p, nullptr, nullptr, 0.f, 0.9f, 0.999f, 1e-8f, 0, xt, R.keep.p + lo, Nl));
+        check(nsk_grad_extra(ctx(), xt, ba_now ? (size_t)nf * 8 + 8 : 4));
+        dist.allreduce_grads();                                                               // the ONE exchange of the iteration
+        check(nsk_grad_extra(ctx(), nullptr, 0));
+        HIPOK(hipMemcpyAsync(D.loss.p + joint_iter, loss_slot, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)nsk_stream(ctx())));
+        check(nsk_adam_step(ctx(), lr, 0.9f, 0.999f, 1e-8f));
+        if (ba_now)                                                                           // every pose at once on the summed gradients (zero for the frames left fixed: no move)
+            check(nsk_adam_vector(ctx(), nf * 8, D.cams.p, xt, D.cam_m.p, D.cam_v.p, BA_cam_lr, 0.9f, 0.999f, 1e-8f, ++ba_step));
     }
     check(nsk_sync(ctx()));
     last_iter_us = (now_us() - t0) / num_joint_iters_;
@@ -878,8 +980,9 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
     decoders.fetch_from_device(!fix_fine, !fix_color);
     last_ba_grad.assign((size_t)nf * 7, 0.f);
     if (any_ba) {                                                                             // :467-489
-        std::vector<float> hg((size_t)nf * 8);
-        D.cam_g.download(hg.data(), hg.size());
+        std::vector<float> hg((size_t)nf * 8 + 8);
+        (sharded ? D.x_ba : D.cam_g).download(hg.data(), hg.size());
+        if (sharded) last_kept_rays = hg[(size_t)nf * 8 + 1];
         for (int i = 0; i < nf; ++i) for (int k = 0; k < 7; ++k) last_ba_grad[(size_t)i * 7 + k] = hg[(size_t)i * 8 + k];
         D.cams.download(h_cam.data(), h_cam.size());
         torch::Tensor bottom = torch::tensor({{0.f, 0.f, 0.f, 1.f}});

@@ -23,7 +23,8 @@ SYMBOLS = (
     "nsk_track_step", "nsk_loss_map", "nsk_loss_track", "nsk_rays_from_pixels", "nsk_rays_backward",
     "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
     "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_prepare_rays", "nsk_map_prepare", "nsk_grad_slab", "nsk_grad_pack", "nsk_grad_unpack", "nsk_allreduce_grads", "nsk_last_call_stats",
-    "nsk_profile_begin", "nsk_profile_end",
+    "nsk_profile_begin", "nsk_profile_end", "nsk_debug_relu_bits", "nsk_debug_preact", "nsk_debug_fetch",
+    "nsk_pose_step_multi", "nsk_set_depth_max_batch", "nsk_grad_extra",
 )
 
 
@@ -345,7 +346,10 @@ class Context:
     @_ordered
     def map_prepare(self, stage, rays_o, rays_d, gt_depth, gt_depth_max=-1.0, flags=GRAD_GRIDS | GRAD_DECODERS):
         """nsk_map_prepare: register the NEXT batch before the current batch's map_step; its sampling and cell sort then ride in that step's
-        composite / backward / Adam launches (include/nsk.h)"""
+        composite / backward / Adam launches (include/nsk.h).  The ray mask remembered for the batch is the BUFFER installed by set_ray_mask
+        when this is called; it is read later (inside the current step, or at the batch's own step), so it must not be the buffer the current
+        step's mask lives in and must stay unchanged until the batch's step has run."""
+        self._prep_keep = (getattr(self, "_ray_mask", None), rays_o, rays_d, gt_depth)      # alive until the next registration
         _chk(lib().nsk_map_prepare(self.h, _stage(stage), rays_o.shape[0], _ptr(rays_o), _ptr(rays_d), _ptr(gt_depth), C.c_float(gt_depth_max), C.c_uint(flags)))
 
     @_ordered
@@ -524,6 +528,31 @@ class Context:
             name, cnt, ms = line.split()
             out[name] = (int(cnt), float(ms))
         return out
+
+    # -- test aids -------------------------------------------------------------------------------------
+    def debug_relu_bits(self, which, M):
+        """[M, 5, 32] bool: the ReLU "input > 0" bits the last step's forward saved for decoder `which`, by sample"""
+        import numpy as np
+        out = np.zeros((M, 5, 32), np.uint8)
+        _chk(lib().nsk_debug_relu_bits(self.h, STAGES[which] if isinstance(which, str) else int(which), int(M), out.ctypes.data_as(C.c_void_p)))
+        return out.astype(bool)
+
+    def debug_fetch(self, what, M):
+        """per-sample array of the last step's workspace: "occ0".."occ2" [M], "rgb4" [M, 4], "g_raw" [M, 4], "z" [M]"""
+        import numpy as np
+        code = {"occ0": 0, "occ1": 1, "occ2": 2, "rgb4": 3, "g_raw": 4, "z": 5}[what]
+        out = np.zeros((M, 4) if code in (3, 4) else (M,), np.float32)
+        _chk(lib().nsk_debug_fetch(self.h, code, int(M), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    @_ordered
+    def debug_preact(self, which, rays_o, rays_d, M):
+        """[M, 5, 32] float32: the ReLU inputs of decoder `which` over the samples of the last step (current matmul mode)"""
+        import torch
+        out = torch.zeros((M, 5, 32), dtype=torch.float32, device=rays_o.device)
+        _chk(lib().nsk_debug_preact(self.h, STAGES[which] if isinstance(which, str) else int(which), int(rays_o.shape[0]), _ptr(rays_o), _ptr(rays_d), _ptr(out)))
+        self.sync()
+        return out.cpu().numpy()
 
     def last_call_stats(self):
         b, f, s = C.c_double(), C.c_double(), C.c_int()

@@ -45,6 +45,9 @@ static inline real r_cos(real x) { return sizeof(real) == 4 ? (real)cosf((float)
 static inline real r_exp(real x) { return sizeof(real) == 4 ? (real)expf((float)x) : (real)exp((double)x); }
 static inline real r_sqrt(real x) { return sizeof(real) == 4 ? (real)sqrtf((float)x) : (real)sqrt((double)x); }
 static inline real r_floor(real x) { return sizeof(real) == 4 ? (real)floorf((float)x) : (real)floor((double)x); }
+/* torch::matmul on the CPU (MKL sgemm) accumulates a dot product with fused multiply-adds in k order: measured here for the K = 3 product of
+ * GaussianFFT (tests/test_oracle.py::test_aten_matmul_k3_is_an_fma_chain: bit-equal on 100 % of 18.6 M elements; the unfused form on 65 %) */
+static inline real r_fma(real a, real b, real c) { return sizeof(real) == 4 ? (real)fmaf((float)a, (float)b, (float)c) : (real)fma((double)a, (double)b, (double)c); }
 static inline real r_abs(real x) { return x < 0 ? -x : x; }
 
 /* ------------------------------------------------------------------------------------------
@@ -266,6 +269,7 @@ typedef struct {
     real e[E_DIM], ce[E_DIM];     /* sin(pB), cos(pB) */
     real c[64];
     real a[5][H_DIM];             /* pre-activation W_i x + b_i */
+    unsigned char on[5][H_DIM];   /* a > 0: the branch torch::relu's backward takes (MLP.cpp:92,98); tests may force it */
     real h[5][H_DIM];             /* block output */
     real out[4];
 } dec_act;
@@ -277,7 +281,7 @@ static void dec_forward(const dec_layout* L, const real* P, const real* p, dec_a
     if (L->has_xyz) {
         const real* B = P + L->oB;
         for (int k = 0; k < E_DIM; ++k) {
-            real s = p[0] * B[k] + p[1] * B[E_DIM + k] + p[2] * B[2 * E_DIM + k];
+            real s = r_fma(p[2], B[2 * E_DIM + k], r_fma(p[1], B[E_DIM + k], p[0] * B[k]));   /* GaussianFFT.cpp:13 matmul, see r_fma */
             A->e[k] = r_sin(s); A->ce[k] = r_cos(s);
             x[k] = A->e[k];
         }
@@ -292,6 +296,7 @@ static void dec_forward(const dec_layout* L, const real* P, const real* p, dec_a
             real s = b[o];
             for (int k = 0; k < nx; ++k) s += W[(size_t)o * nx + k] * x[k];
             A->a[i][o] = s;
+            A->on[i][o] = s > 0;
             real h = s > 0 ? s : 0;
             if (L->has_xyz) {
                 const real* Fw = P + L->oFw[i]; const real* Fb = P + L->oFb[i];
@@ -348,7 +353,7 @@ static void dec_backward(const dec_layout* L, const real* P, const real* p, cons
             for (int k = 0; k < H_DIM; ++k) x[pre + k] = A->h[2][k];
         } else { for (int k = 0; k < H_DIM; ++k) x[k] = A->h[i - 1][k]; }
         real g_a[H_DIM];
-        for (int o = 0; o < H_DIM; ++o) g_a[o] = A->a[i][o] > 0 ? g_h[o] : 0;
+        for (int o = 0; o < H_DIM; ++o) g_a[o] = A->on[i][o] ? g_h[o] : 0;
         if (L->has_xyz) {
             const real* Fw = P + L->oFw[i];
             for (int k = 0; k < L->c_dim; ++k) {
@@ -499,10 +504,11 @@ NSO_API int nso_render_forward(const nso_opts* o, const nso_grid* grids, const r
  * Upstream: g_rgb [N][3], g_depth [N], g_var [N] (NULL = depth_var detached).
  * Accumulates into (each may be NULL): g_grids[l] ([C][Z][Y][X]), g_P[w] (packed decoder grads),
  * g_rays_o / g_rays_d [N][3] (overwritten).  Single-threaded when grads are accumulated. */
-NSO_API int nso_render_backward(const nso_opts* o, const nso_grid* grids, const real* const* P, int stage, int N,
+static int render_backward_impl(const nso_opts* o, const nso_grid* grids, const real* const* P, int stage, int N,
                                 const real* rays_o, const real* rays_d, const real* gt_depth, real gt_depth_max,
                                 const real* g_rgb, const real* g_depth, const real* g_var,
-                                real* const* g_grids, real* const* g_P, real* g_rays_o, real* g_rays_d)
+                                real* const* g_grids, real* const* g_P, real* g_rays_o, real* g_rays_d,
+                                const unsigned char* const* relu, const unsigned char* sigma_on)
 {
     dec_layout L[4]; for (int i = 0; i < 4; ++i) make_layout(i, &L[i]);
     if (o->n_samples + o->n_surface > MAX_S) return -1;
@@ -532,6 +538,10 @@ NSO_API int nso_render_backward(const nso_opts* o, const nso_grid* grids, const 
             real p[3];
             for (int k = 0; k < 3; ++k) p[k] = ro[k] + rd[k] * z[s];
             point_forward(o, grids, P, L, stage, p, &st[s]);
+            if (relu) for (int q = 0; q < 3; ++q) {               /* test aid: the backward takes the given ReLU branches */
+                int wd = STAGE_DECODERS[stage][q];
+                if (wd >= 0 && relu[wd]) memcpy(st[s].act[wd].on, relu[wd] + ((size_t)n * S + s) * 5 * H_DIM, 5 * H_DIM);
+            }
             memcpy(raw + 4 * s, st[s].raw, 4 * sizeof(real));
         }
         composite_forward(o, S, z, rd, raw, al, T, w, rgb, &D, &V);
@@ -559,7 +569,8 @@ NSO_API int nso_render_backward(const nso_opts* o, const nso_grid* grids, const 
                 real dist = dz * nrm;
                 real rs = sg > 0 ? sg : 0;
                 real ex = r_exp(-rs * dist);
-                g_sigma = sg > 0 ? g_alpha * dist * ex : 0;
+                const int on = sigma_on ? sigma_on[(size_t)n * S + s] : (sg > 0);     /* relu(sigma), utils.h:160; tests may force the branch */
+                g_sigma = on ? g_alpha * dist * ex : 0;
                 g_nrm += g_alpha * rs * ex * dz;
             }
             if (!st[s].inb) g_sigma = 0;                      /* raw[~mask,3]=100 is a constant */
@@ -593,6 +604,176 @@ NSO_API int nso_render_backward(const nso_opts* o, const nso_grid* grids, const 
         }
     }
     free(st);
+    }
+    return 0;
+}
+
+NSO_API int nso_render_backward(const nso_opts* o, const nso_grid* grids, const real* const* P, int stage, int N,
+                                const real* rays_o, const real* rays_d, const real* gt_depth, real gt_depth_max,
+                                const real* g_rgb, const real* g_depth, const real* g_var,
+                                real* const* g_grids, real* const* g_P, real* g_rays_o, real* g_rays_d)
+{
+    return render_backward_impl(o, grids, P, stage, N, rays_o, rays_d, gt_depth, gt_depth_max, g_rgb, g_depth, g_var,
+                                g_grids, g_P, g_rays_o, g_rays_d, NULL, NULL);
+}
+
+/* Test aid (not in the reference): the same backward with the branch of every hidden ReLU GIVEN instead of taken from
+ * this evaluation's own pre-activations.  relu[w] (w = decoder 0..3, NULL = own branches): [N*S][5][32] bytes, 1 = "input > 0".
+ * sigma_on[N*S] (or NULL): likewise the branch of relu(sigma) in the density compositing (utils.h:160).
+ * The forward values are untouched.  With the branches another fp32 evaluation took (the HIP path's saved bits), the gradient
+ * is one smooth function of the inputs for both, so ALL rays can be compared at the contract's tolerance. */
+NSO_API int nso_render_backward_forced(const nso_opts* o, const nso_grid* grids, const real* const* P, int stage, int N,
+                                       const real* rays_o, const real* rays_d, const real* gt_depth, real gt_depth_max,
+                                       const real* g_rgb, const real* g_depth, const real* g_var,
+                                       real* const* g_grids, real* const* g_P, real* g_rays_o, real* g_rays_d,
+                                       const unsigned char* const* relu, const unsigned char* sigma_on)
+{
+    return render_backward_impl(o, grids, P, stage, N, rays_o, rays_d, gt_depth, gt_depth_max, g_rgb, g_depth, g_var,
+                                g_grids, g_P, g_rays_o, g_rays_d, relu, sigma_on);
+}
+
+/* Test aid: the hidden ReLU inputs of decoder `which` at every sample, a_out[N*S][5][32] (tools/relu_flips.py counts the
+ * branches on which two evaluations disagree), and optionally raw_out[N*S][4]. */
+NSO_API int nso_preacts(const nso_opts* o, const nso_grid* grids, const real* const* P, int stage, int which, int N,
+                        const real* rays_o, const real* rays_d, const real* gt_depth, real gt_depth_max, real* a_out)
+{
+    dec_layout L[4]; for (int i = 0; i < 4; ++i) make_layout(i, &L[i]);
+    if (gt_depth && gt_depth_max < 0) gt_depth_max = nso_depth_max(N, gt_depth);
+#pragma omp parallel for schedule(dynamic, 4) if (N > 64)
+    for (int n = 0; n < N; ++n) {
+        pt_state st; real z[MAX_S];
+        int S = ray_z_vals(o, n, rays_o + 3 * n, rays_d + 3 * n, gt_depth != NULL, gt_depth ? gt_depth[n] : 0,
+                           gt_depth_max, z);
+        for (int s = 0; s < S; ++s) {
+            real p[3];
+            for (int k = 0; k < 3; ++k) p[k] = rays_o[3 * n + k] + rays_d[3 * n + k] * z[s];
+            point_forward(o, grids, P, L, stage, p, &st);
+            memcpy(a_out + ((size_t)n * S + s) * 5 * H_DIM, st.act[which].a, sizeof(real) * 5 * H_DIM);
+        }
+    }
+    return 0;
+}
+
+/* Test aid: how far the ReLU inputs of ANY fp32 evaluation of this path can lie from the exact ones -- a first-order error bound,
+ * tau_out[N*S][5][32] for decoder `which`, evaluated at the samples with want[n*S+s] != 0 (want == NULL: all; the rest is left untouched).
+ * Error sources, u = 2^-24 per fp32 operation:
+ *   z      a handful of roundings of magnitudes <= the ray's largest z:                      dz  = 8 u z_max
+ *   p      = fl(o + fl(d z)) (src/Renderer.cpp:121):                                        dp_i = |d_i| dz + u (|d_i z| + |p_i|)
+ *   s_k    = the K = 3 FMA chain of p.B (GaussianFFT.cpp:13):                               ds_k = sum_i |B_ik| dp_i + u (|t0| + |t0 + t1| + |s_k|)
+ *   e_k    = sin(s_k) with a sine accurate to sin_err absolute (glibc: 6e-8; v_sin_f32 + reduction: 3.2e-7):   de_k = ds_k + sin_err
+ *   c_k    the trilinear feature: moving the lookup by dp moves it by at most (cells moved) x (spread of the 8 corner values), plus its own sums
+ *   r_l[o] the local rounding of block l: a_l = b + sum_k W[o,k] x_k with every product in two fp16 / three bf16 pieces (2^-22 relative)
+ *          summed in any order (K u), likewise fc_l c, and the sums that join them:
+ *                                                      r = (K u + 2^-21) sum_k |W[o,k] x_k| + u |b| + the same for fc_l c + sum_k |F[o,k]| dc_k + 2 u |h|
+ * The sources are carried through the network by the EXACT first-order map of this sample (the Jacobians d a_l / d source with this
+ * sample's ReLU branches, so that paths that cancel do cancel), and only their signs are taken worst-case:
+ *                                                      tau_l[o] = sum_src |d a_l[o] / d src| mag(src) + (local part of r_l[o]).
+ * A branch of an fp32 evaluation that differs from this (exact) evaluation's must have |a| <= tau (to first order in u);
+ * tests/test_gpu_relu.py asserts it for every ReLU of the HIP forward that took the other branch.  Worst-case signs over 93 + 128 sources:
+ * ~10x above the rms error, three orders below a typical |a|. */
+#define NSRC (E_DIM + 4 * H_DIM)
+NSO_API int nso_preact_bounds(const nso_opts* o, const nso_grid* grids, const real* const* P, int stage, int which, int N,
+                              const real* rays_o, const real* rays_d, const real* gt_depth, real gt_depth_max, real sin_err,
+                              const unsigned char* want, real* tau_out)
+{
+    dec_layout L[4]; for (int i = 0; i < 4; ++i) make_layout(i, &L[i]);
+    if (which < 1 || which > 3) return -1;
+    if (gt_depth && gt_depth_max < 0) gt_depth_max = nso_depth_max(N, gt_depth);
+    const real u = (real)5.9604644775390625e-08, u22 = (real)4.76837158203125e-07;
+    const dec_layout* Lw = &L[which];
+    const real* Pw = P[which];
+#pragma omp parallel for schedule(dynamic, 1) if (N > 8)
+    for (int n = 0; n < N; ++n) {
+        pt_state st; real z[MAX_S];
+        const real* ro = rays_o + 3 * n; const real* rd = rays_d + 3 * n;
+        int S = ray_z_vals(o, n, ro, rd, gt_depth != NULL, gt_depth ? gt_depth[n] : 0, gt_depth_max, z);
+        int any = want == NULL;
+        for (int s = 0; s < S && !any; ++s) any = want[(size_t)n * S + s] != 0;
+        if (!any) continue;
+        real (*Jh)[NSRC] = (real (*)[NSRC])malloc(sizeof(real) * H_DIM * NSRC);      /* d h_{l-1} / d source */
+        real (*Jh2)[NSRC] = (real (*)[NSRC])malloc(sizeof(real) * H_DIM * NSRC);     /* d h_2 / d source (skip connection of block 3) */
+        real (*Ja)[NSRC] = (real (*)[NSRC])malloc(sizeof(real) * H_DIM * NSRC);
+        const real dz = 8 * u * r_abs(z[S - 1]);
+        for (int s = 0; s < S; ++s) {
+            if (want && !want[(size_t)n * S + s]) continue;
+            real p[3], dp[3];
+            for (int k = 0; k < 3; ++k) {
+                p[k] = ro[k] + rd[k] * z[s];
+                dp[k] = r_abs(rd[k]) * dz + u * (r_abs(rd[k] * z[s]) + r_abs(p[k]));
+            }
+            point_forward(o, grids, P, L, stage, p, &st);
+            const dec_act* A = &st.act[which];
+            real mag[NSRC], dc[64];
+            const real* B = Pw + Lw->oB;
+            for (int k = 0; k < E_DIM; ++k) {
+                real t0 = p[0] * B[k], t1 = p[1] * B[E_DIM + k], t2 = p[2] * B[2 * E_DIM + k];
+                real ds = r_abs(B[k]) * dp[0] + r_abs(B[E_DIM + k]) * dp[1] + r_abs(B[2 * E_DIM + k]) * dp[2] +
+                          u * (r_abs(t0) + r_abs(t0 + t1) + r_abs(t0 + t1 + t2));
+                mag[k] = ds + sin_err;
+            }
+            for (int half = 0; half < (which == 2 ? 2 : 1); ++half) {          /* fine: its own level, then the middle level (MLP.cpp:79-84) */
+                const nso_grid* g = &grids[half == 0 ? which : 1];
+                tri_coord tc; tri_setup(g, o->bound, p, &tc);
+                const size_t cs = (size_t)g->Z * g->Y * g->X;
+                real shift = tc.gmul[0] * dp[0] + tc.gmul[1] * dp[1] + tc.gmul[2] * dp[2] + 6 * u * (real)(g->X + g->Y + g->Z);
+                for (int c = 0; c < g->C; ++c) {
+                    real lo = 0, hi = 0, am = 0; int first = 1;
+                    for (int q = 0; q < 8; ++q) {
+                        int ix = tc.i0[0] + (q & 1), iy = tc.i0[1] + ((q >> 1) & 1), iz = tc.i0[2] + (q >> 2);
+                        real v = tri_inb(g, ix, iy, iz) ? g->v[c * cs + ((size_t)iz * g->Y + iy) * g->X + ix] : 0;
+                        if (first || v < lo) lo = v;
+                        if (first || v > hi) hi = v;
+                        if (r_abs(v) > am) am = r_abs(v);
+                        first = 0;
+                    }
+                    dc[32 * half + c] = shift * (hi - lo) * 3 + 16 * u * am;     /* three axes: each lerp moves by at most shift x spread */
+                }
+            }
+            real* tau = tau_out + ((size_t)n * S + s) * 5 * H_DIM;
+            for (int i = 0; i < 5; ++i) {
+                const int nx = Lw->in_dim[i];
+                const real* W = Pw + Lw->oW[i]; const real* b = Pw + Lw->ob[i];
+                const real* Fw = Pw + Lw->oFw[i]; const real* Fb = Pw + Lw->oFb[i];
+                const int nsrc = E_DIM + (i < 4 ? i : 4) * H_DIM;               /* sources that exist before block i */
+                for (int q = 0; q < H_DIM; ++q) {
+                    const real* w = W + (size_t)q * nx;
+                    real loc = 0;                                                /* local rounding of a_i[q] */
+                    for (int c = 0; c < NSRC; ++c) Ja[q][c] = 0;
+                    if (i == 0 || i == 3) {
+                        for (int k = 0; k < E_DIM; ++k) { Ja[q][k] = w[k]; loc += r_abs(w[k] * A->e[k]); }
+                        if (i == 3) for (int k = 0; k < H_DIM; ++k) {
+                            const real wk = w[E_DIM + k];
+                            loc += r_abs(wk * A->h[2][k]);
+                            for (int c = 0; c < nsrc; ++c) Ja[q][c] += wk * Jh2[k][c];
+                        }
+                    } else {
+                        for (int k = 0; k < H_DIM; ++k) {
+                            const real wk = w[k];
+                            loc += r_abs(wk * A->h[i - 1][k]);
+                            for (int c = 0; c < nsrc; ++c) Ja[q][c] += wk * Jh[k][c];
+                        }
+                    }
+                    loc = ((real)nx * u + 2 * u22) * loc + u * r_abs(b[q]);
+                    real t = loc;
+                    for (int c = 0; c < nsrc; ++c) t += r_abs(Ja[q][c]) * mag[c];
+                    tau[i * H_DIM + q] = t;
+                    if (i < 4) {                                                 /* block output: relu(a) + fc c + bc; its local error becomes source (i, q) */
+                        real flin = 0, fmag = 0;
+                        for (int k = 0; k < Lw->c_dim; ++k) { flin += r_abs(Fw[(size_t)q * Lw->c_dim + k]) * dc[k]; fmag += r_abs(Fw[(size_t)q * Lw->c_dim + k] * A->c[k]); }
+                        mag[E_DIM + i * H_DIM + q] = loc + flin + ((real)Lw->c_dim * u + 2 * u22) * fmag + u * r_abs(Fb[q]) + 2 * u * r_abs(A->h[i][q]);
+                    }
+                }
+                if (i < 4) {
+                    for (int q = 0; q < H_DIM; ++q) {
+                        const int on = A->a[i][q] > 0;
+                        for (int c = 0; c < NSRC; ++c) Jh[q][c] = on ? Ja[q][c] : 0;
+                        Jh[q][E_DIM + i * H_DIM + q] = 1;
+                    }
+                    if (i == 2) memcpy(Jh2, Jh, sizeof(real) * H_DIM * NSRC);
+                }
+            }
+        }
+        free(Jh); free(Jh2); free(Ja);
     }
     return 0;
 }

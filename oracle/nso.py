@@ -136,7 +136,9 @@ class Oracle:
         return out
 
     def render_backward(self, opts, grids, decoders, stage, rays_o, rays_d, gt_depth, gt_depth_max, g_rgb, g_depth,
-                        g_var=None, want_grids=True, want_decoders=True, want_rays=True):
+                        g_var=None, want_grids=True, want_decoders=True, want_rays=True, relu=None, sigma_on=None):
+        """relu (test aid): dict decoder name -> [N*S, 5, 32] bool, the ReLU branches the backward takes instead of its own;
+        sigma_on: [N*S] bool, likewise the branch of relu(sigma) in the compositing"""
         ro, rd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3))
         N = ro.shape[0]
         gd = None if gt_depth is None else self.arr(gt_depth, (N,))
@@ -155,13 +157,56 @@ class Oracle:
                 gp_ptr[i] = gp[name].ctypes.data
         gro = np.zeros((N, 3), self.dt) if want_rays else None
         grd = np.zeros((N, 3), self.dt) if want_rays else None
-        rc = self.lib.nso_render_backward(C.byref(opts), ga, da, _stage_id(stage), N, self._p(ro), self._p(rd),
-                                          self._p(gd), self.creal(gt_depth_max), self._p(grgb), self._p(gdep),
-                                          self._p(gvar), gg_ptr if want_grids else None,
-                                          gp_ptr if want_decoders else None, self._p(gro), self._p(grd))
+        args = (C.byref(opts), ga, da, _stage_id(stage), N, self._p(ro), self._p(rd),
+                self._p(gd), self.creal(gt_depth_max), self._p(grgb), self._p(gdep),
+                self._p(gvar), gg_ptr if want_grids else None,
+                gp_ptr if want_decoders else None, self._p(gro), self._p(grd))
+        if relu is None and sigma_on is None:
+            rc = self.lib.nso_render_backward(*args)
+        else:
+            relu = relu or {}
+            S = opts.n_samples + (opts.n_surface if gd is not None else 0)
+            rp, keep = (C.c_void_p * 4)(), []
+            for i, name in enumerate(LEVELS):
+                if name in relu and relu[name] is not None:
+                    b = np.ascontiguousarray(np.asarray(relu[name]).astype(np.uint8).reshape(N * S, 5, 32))
+                    keep.append(b)
+                    rp[i] = b.ctypes.data
+            so = None if sigma_on is None else np.ascontiguousarray(np.asarray(sigma_on).astype(np.uint8).reshape(N * S))
+            rc = self.lib.nso_render_backward_forced(*args, rp, self._p(so))
         assert rc == 0
         return dict(g_grids=gg, g_decoders=gp, g_rays_o=gro, g_rays_d=grd)
 
+
+    def preacts(self, opts, grids, decoders, stage, which, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0):
+        """[N*S, 5, 32]: the hidden ReLU inputs of decoder `which` at every sample (test aid, see nso.c)"""
+        ro, rd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3))
+        N = ro.shape[0]
+        gd = None if gt_depth is None else self.arr(gt_depth, (N,))
+        S = opts.n_samples + (opts.n_surface if gd is not None else 0)
+        ga, k1 = self._grids(grids)
+        da, k2 = self._decs(decoders)
+        a = np.zeros((N * S, 5, 32), self.dt)
+        rc = self.lib.nso_preacts(C.byref(opts), ga, da, _stage_id(stage), _stage_id(which), N, self._p(ro), self._p(rd),
+                                  self._p(gd), self.creal(gt_depth_max), self._p(a))
+        assert rc == 0
+        return a
+
+    def preact_bounds(self, opts, grids, decoders, stage, which, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0, sin_err=3.2e-7, want=None):
+        """[N*S, 5, 32]: first-order bound on |ReLU input of an fp32 evaluation - exact| at the samples with want[N*S] set (None: all; zeros
+        elsewhere) (test aid, see nso.c nso_preact_bounds)"""
+        ro, rd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3))
+        N = ro.shape[0]
+        gd = None if gt_depth is None else self.arr(gt_depth, (N,))
+        S = opts.n_samples + (opts.n_surface if gd is not None else 0)
+        ga, k1 = self._grids(grids)
+        da, k2 = self._decs(decoders)
+        tau = np.zeros((N * S, 5, 32), self.dt)
+        wt = None if want is None else np.ascontiguousarray(np.asarray(want).astype(np.uint8).reshape(N * S))
+        rc = self.lib.nso_preact_bounds(C.byref(opts), ga, da, _stage_id(stage), _stage_id(which), N, self._p(ro), self._p(rd),
+                                        self._p(gd), self.creal(gt_depth_max), self.creal(sin_err), self._p(wt), self._p(tau))
+        assert rc == 0
+        return tau
 
     def ray_fragility(self, opts, grids, decoders, stage, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0):
         """min |ReLU input| per ray (test aid, see nso.c)"""

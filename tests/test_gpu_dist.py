@@ -253,6 +253,98 @@ def test_map_prepare_gives_the_unprepared_steps(case):
     assert rel_l2(d1, d0) < 1e-4
 
 
+@pytest.mark.parametrize("order", ["capture-with-pending", "replay-between", "replay-after-swap"])
+def test_map_prepare_and_graphs_do_not_step_on_each_other(order):
+    """A batch registered with nsk_map_prepare around a hipGraph capture or replay (round 3's advisor finding): the capture may not record the
+    batch's pending sampling / cell sort instead of running it, and a replay may neither add onto a histogram that still holds the batch's counts
+    nor write into the buffer set the batch lives in.  Sequence: prepare(B), step(A), [capture or replay of a graph of step C], step(B), each
+    with its optimiser step, against the same steps with nothing prepared: same losses, same parameters (up to the order of the gradient sums).
+    "replay-after-swap": the graph was captured before a prepared step swapped the two buffer sets, so its recorded set is the one B sits in."""
+    sc = scenes.make_scene(11, grid_std=0.05)
+    B = []
+    for k in range(3):
+        r = scenes.make_rays(60 + k, 400, sc["bound"], n_frames=5)
+        B.append([cu(r[x]) for x in ("rays_o", "rays_d", "gt_depth", "gt_color")] + [float(r["gt_depth"].max())])
+    out = []
+    for prepare in (False, True):
+        ctx = make_ctx(sc, trainable=["color"])
+        ctx.set_sort_mode(1)
+        loss = torch.zeros(1, device="cuda")
+        losses = []
+
+        def step(b, prep=None):
+            if prep is not None and prepare:
+                ctx.map_prepare("color", B[prep][0], B[prep][1], B[prep][2], B[prep][4], flags=3)
+            ctx.map_step("color", *B[b][:4], B[b][4], 0.2, True, flags=3, loss=loss)
+            ctx.adam_step(LR)
+
+        with torch.cuda.stream(ctx.tstream):
+            step(2); losses.append(float(loss))                          # sizes the workspaces (a capture may not grow them)
+            gid = None
+            if order != "capture-with-pending":
+                ctx.graph_begin(); step(2); gid = ctx.graph_end()
+            if order == "replay-after-swap":                                 # one prepared step: the sets swap after the capture
+                step(0, prep=1); losses.append(float(loss))
+                step(1, prep=0); losses.append(float(loss))
+            else:
+                step(0, prep=1); losses.append(float(loss))
+            # batch 1 (or 0) is now prepared: sampled inside the last step's composite launch, sort offsets / placement in its backward / Adam
+            if order == "capture-with-pending":
+                ctx.map_prepare("color", B[0][0], B[0][1], B[0][2], B[0][4], flags=3) if prepare else None
+                ctx.graph_begin(); step(2); gid = ctx.graph_end()
+                ctx.graph_launch(gid); losses.append(float(loss))
+                step(1); losses.append(float(loss))
+                step(0); losses.append(float(loss))
+            else:
+                ctx.graph_launch(gid); losses.append(float(loss))
+                nxt = 0 if order == "replay-after-swap" else 1
+                step(nxt); losses.append(float(loss))
+                ctx.graph_launch(gid); losses.append(float(loss))
+                step(1 - nxt); losses.append(float(loss))
+        ctx.sync()
+        out.append((losses, {k: ctx.grid_download(k) for k in ("middle", "fine", "color")}, ctx.decoder_download("color")))
+        ctx.close()
+    (l0, g0, d0), (l1, g1, d1) = out
+    assert np.all(np.isfinite(l1)) and np.allclose(l0, l1, rtol=1e-5), (l0, l1)
+    for k in g0:
+        assert np.isfinite(g1[k]).all()
+        assert rel_l2(g1[k] - sc["grids"][k], g0[k] - sc["grids"][k]) < 5e-3, k
+    assert rel_l2(d1, d0) < 1e-4
+
+
+def test_map_prepare_reads_the_mask_buffer_installed_at_registration():
+    """The keep mask of a prepared batch is the BUFFER installed (nsk_set_ray_mask) when nsk_map_prepare was called; its contents are read when
+    the batch's sampling runs (inside the current step's composite launch), so it must be a different buffer from the current step's mask and
+    stay unchanged until the batch's own step (include/nsk.h).  Two mask buffers used that way give the unprepared steps."""
+    sc = scenes.make_scene(11, grid_std=0.05)
+    B, K = [], []
+    for k in range(2):
+        r = scenes.make_rays(80 + k, 400, sc["bound"], n_frames=5)
+        B.append([cu(r[x]) for x in ("rays_o", "rays_d", "gt_depth", "gt_color")])
+        keep = np.ones(400, np.uint8); keep[k::3] = 0
+        K.append(cu(keep, dtype=torch.uint8))
+    out = []
+    for prepare in (False, True):
+        ctx = make_ctx(sc, trainable=["color"])
+        ctx.set_sort_mode(1)
+        loss = torch.zeros(1, device="cuda")
+        losses = []
+        with torch.cuda.stream(ctx.tstream):
+            for i in range(4):
+                cur, nxt = i % 2, (i + 1) % 2
+                if prepare:
+                    ctx.set_ray_mask(K[nxt])
+                    ctx.map_prepare("color", B[nxt][0], B[nxt][1], B[nxt][2], -1.0, flags=3)
+                ctx.set_ray_mask(K[cur])
+                ctx.map_step("color", *B[cur], -1.0, 0.2, True, flags=3, loss=loss)
+                ctx.adam_step(LR)
+                losses.append(float(loss))
+        out.append((losses, ctx.grid_download("color")))
+        ctx.close()
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-5), (out[0][0], out[1][0])
+    assert rel_l2(out[1][1] - sc["grids"]["color"], out[0][1] - sc["grids"]["color"]) < 5e-3
+
+
 def test_rccl_communicator_bootstrapped_from_a_process_group():
     """nice-slam-cpp_amd/dist.py::rccl_comm_from_group (what bench.py does at N > 1: ncclUniqueId drawn by rank 0, its 128 bytes broadcast over the
     process group, ncclCommInitRank per rank) on a one-rank "nccl" process group: the communicator must come back and nsk_allreduce_grads over it

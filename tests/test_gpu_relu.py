@@ -1,0 +1,132 @@
+"""GPU parity tests (-m gpu) of the gradient at the kinks, at the full size of every BASELINE config (round 4).
+
+The render is piecewise smooth: every hidden ReLU (src/models/MLP.cpp:92,98), the relu(sigma) of the density compositing
+(include/torchlib/utils.h:160) and the L1 losses (src/Mapper.cpp:435-442) switch branch at zero, and a gradient jumps there.  Two fp32
+evaluations of the same batch put the ~10^8 branch inputs of a K3 step on different sides of zero a few hundred times (the fp32 CPU oracle
+against the fp64 one: ~450 hidden-ReLU branches at K3; measured with tools/relu_flips.py), and two or three rays then carry 90 % of an
+all-rays gradient difference of 1e-4 .. 5e-4.  Thresholding rays by how close they come to a kink (test_gpu_configs.py's strict arm) keeps a
+fifth of the rays at K3.  This file states the contract in the two halves it really has, over ALL rays:
+
+  legitimacy   every branch the HIP forward took differently from the exact (fp64) evaluation has an input within the first-order rounding
+               bound tau of zero -- tau is DERIVED per sample and unit from the fp32 error model (oracle/nso.c nso_preact_bounds: ulp-level
+               errors of z and p, times B, through the exact Jacobian of that sample), nothing tuned -- and the HIP forward disagrees with the
+               fp32 oracle on no more branches than the fp32 oracle disagrees with the exact evaluation;
+  smooth part  with the branches GIVEN (the fp32 oracle's backward takes the HIP forward's hidden-ReLU bits, its relu(sigma) branches and its
+               L1 signs: nso_render_backward_forced) the gradient is one smooth function for both, and every trained level and the colour decoder
+               must agree within 1e-4 relative L2 -- 100 % of the rays, no escape clause.
+"""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from gpu_util import cu, make_ctx
+from scenes import rel_l2
+from test_gpu_configs import LEVELS, _strict_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+S = 48
+SIN_ERR = 3.2e-7          # v_sin_f32 (1.25e-7 abs, tools/ubench/vsin.hip) + the two-term reduction in revolutions (1.9e-7 rad)
+
+
+def hip_step(sc, rays, stage, gmax, sort_mode=-1, matmul_mode=2):
+    """one mapping step on the GPU; returns gradients, the branches its forward took and what it rendered"""
+    N = rays["rays_o"].shape[0]
+    M = N * S
+    decs = list(LEVELS[stage])
+    ctx = make_ctx(sc, trainable=["color"] if stage == "color" else [])
+    ctx.set_sort_mode(sort_mode)
+    ctx.set_matmul_mode(matmul_mode)
+    loss_t = torch.zeros(1, device="cuda")
+    out = (torch.zeros(N, 3, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"))
+    ro, rd = cu(rays["rays_o"]), cu(rays["rays_d"])
+    ctx.map_step(stage, ro, rd, cu(rays["gt_depth"]), cu(rays["gt_color"]), gmax, 0.5, stage == "color", flags=3 if stage == "color" else 1,
+                 loss=loss_t, outputs=out)
+    r = dict(loss=float(loss_t), rgb=out[0].cpu().numpy(), depth=out[1].cpu().numpy())
+    r["grads"] = {k: ctx.grid_download(k, grad=True) for k in decs}
+    if stage == "color":
+        r["grads"]["colour decoder"] = ctx.decoder_download("color", grad=True)
+    r["bits"] = {k: ctx.debug_relu_bits(k, M) for k in decs}
+    r["pre"] = {k: ctx.debug_preact(k, ro, rd, M) for k in decs}
+    sig = ctx.debug_fetch("occ1", M)
+    if "fine" in decs:
+        sig = ctx.debug_fetch("occ2", M) + sig                      # fine_occ + middle_occ, the compositing kernel's own sum (NICE.cpp:40,49)
+    r["sigma"] = sig
+    ctx.close()
+    return r
+
+
+def forced_oracle_grads(o, sc, rays, stage, gmax, hip):
+    """the oracle's gradients with every branch taken as the HIP forward took it: hidden ReLUs, relu(sigma), the signs of the L1 residuals"""
+    _, g_d, g_c = o.loss_map(hip["depth"], hip["rgb"], rays["gt_depth"], rays["gt_color"], 0.5, stage == "color")       # signs of the HIP residuals
+    bw = o.render_backward(o.opts(sc["bound"]), sc["grids"], sc["decoders"], stage, rays["rays_o"], rays["rays_d"], rays["gt_depth"], gmax, g_c, g_d, None,
+                           want_rays=False, relu=hip["bits"], sigma_on=hip["sigma"] > 0)
+    g = dict(bw["g_grids"])
+    if stage == "color":
+        g["colour decoder"] = bw["g_decoders"]["color"]
+    return g
+
+
+@pytest.mark.parametrize("case,sort_mode", [("K2-color", -1), ("K2-color", 0), ("K3-fine", -1), ("K3-color", -1), ("K4-shard", -1)])
+def test_gradients_with_the_forward_s_branches_all_rays(case, sort_mode, oracle32, oracle64):
+    sc, rays, stage, gmax = _strict_case(case)
+    if gmax is None:
+        gmax = float(rays["gt_depth"].max())
+    N = rays["rays_o"].shape[0]
+    decs = list(LEVELS[stage])
+    hip = hip_step(sc, rays, stage, gmax, sort_mode)
+    op32, op64 = oracle32.opts(sc["bound"]), oracle64.opts(sc["bound"])
+    args = (rays["rays_o"], rays["rays_d"], rays["gt_depth"], gmax)
+    # ---- legitimacy of every branch that differs from the exact evaluation --------------------------------------------------------------
+    n_hip_f32 = n_f32_f64 = n_hip_f64 = 0
+    worst = 0.0
+    for k in decs:
+        a64 = oracle64.preacts(op64, sc["grids"], sc["decoders"], stage, k, *args)
+        a32 = oracle32.preacts(op32, sc["grids"], sc["decoders"], stage, k, *args)
+        assert int(((hip["pre"][k] > 0) != hip["bits"][k]).sum()) == 0, k       # the dump body and the step's body are the same arithmetic, bit for bit
+        f64 = hip["bits"][k] != (a64 > 0)
+        f32 = hip["bits"][k] != (a32 > 0)
+        o32 = (a32 > 0) != (a64 > 0)
+        n_hip_f64 += int(f64.sum()); n_hip_f32 += int(f32.sum()); n_f32_f64 += int(o32.sum())
+        d32 = hip["pre"][k].astype(np.float64) - a32
+        d64 = hip["pre"][k].astype(np.float64) - a64
+        e32 = a32.astype(np.float64) - a64
+        print("%s decoder %-6s: ReLU inputs hip-vs-fp32-oracle rms %.2e max %.2e | hip-vs-fp64 rms %.2e | fp32-oracle-vs-fp64 rms %.2e | branches: hip/f32 %d, hip/f64 %d, f32/f64 %d of %d" % (
+            case, k, np.sqrt((d32 ** 2).mean()), np.abs(d32).max(), np.sqrt((d64 ** 2).mean()), np.sqrt((e32 ** 2).mean()), f32.sum(), f64.sum(), o32.sum(), f64.size))
+        # the HIP forward's ReLU inputs are as close to exact as the fp32 oracle's (same geometry arithmetic; sine and matrix products differ)
+        assert np.sqrt((d64 ** 2).mean()) < 1.5 * np.sqrt((e32 ** 2).mean()) + 1e-7
+        if f64.any():
+            want = f64.reshape(N * S, -1).any(axis=1)
+            tau = oracle64.preact_bounds(op64, sc["grids"], sc["decoders"], stage, k, *args, sin_err=SIN_ERR, want=want)
+            ratio = np.abs(a64[f64]) / tau[f64]
+            worst = max(worst, float(ratio.max()))
+            assert (ratio <= 1.0).all(), (case, k, float(ratio.max()))
+    print("%s: %d hidden-ReLU branches differ from the exact evaluation, the largest input among them at %.3f of its derived bound; "
+          "hip vs fp32 oracle %d, fp32 oracle vs exact %d" % (case, n_hip_f64, worst, n_hip_f32, n_f32_f64))
+    assert n_hip_f32 <= max(10, n_f32_f64), (n_hip_f32, n_f32_f64)
+    # ---- the smooth part: all rays, branches given, no escape clause -------------------------------------------------------------------
+    ref = forced_oracle_grads(oracle32, sc, rays, stage, gmax, hip)
+    errs = {k: rel_l2(hip["grads"][k], ref[k]) for k in hip["grads"]}
+    print("%s, sort mode %d: all %d rays, branches as the HIP forward took them: gradient errors vs the fp32 oracle %s" % (
+        case, sort_mode, N, {k: "%.1e" % v for k, v in errs.items()}))
+    for k, e in errs.items():
+        assert e < TOL, (case, sort_mode, k, e)
+
+
+def test_forward_bodies_agree_on_every_branch(oracle32):
+    """The three forward bodies (fp32 MFMA, three bf16 pieces, two fp16 pieces) see the same sample points and the same embedding arguments bit
+    for bit (mul_rn / the explicit FMA chain of embed(), nsk_device.h: no compiler-chosen contraction), so they part only where the matrix
+    products' last bits decide a branch: a handful of the 1.15e8 ReLU inputs of a K3 step.  Until round 4 two instantiations of ONE body
+    differed on ~130 of them, which is what moved the colour level's all-rays gradient between 1.2e-4 and 3.5e-4 from the oracle."""
+    sc, rays, stage, _ = _strict_case("K3-color")
+    gmax = float(rays["gt_depth"].max())
+    runs = {m: hip_step(sc, rays, stage, gmax, matmul_mode=m) for m in (0, 1, 2)}
+    for k in LEVELS[stage]:
+        d01 = int((runs[0]["bits"][k] != runs[1]["bits"][k]).sum())
+        d12 = int((runs[1]["bits"][k] != runs[2]["bits"][k]).sum())
+        dp = np.abs(runs[0]["pre"][k] - runs[2]["pre"][k])
+        print("decoder %-6s: branches fp32-MFMA vs 3 x bf16: %d, 3 x bf16 vs 2 x fp16: %d of %d; ReLU inputs fp32-MFMA vs 2 x fp16: rms %.2e max %.2e" % (
+            k, d01, d12, runs[0]["bits"][k].size, np.sqrt((dp.astype(np.float64) ** 2).mean()), dp.max()))
+        assert d01 <= 40 and d12 <= 40, (k, d01, d12)
+        assert np.sqrt((dp.astype(np.float64) ** 2).mean()) < 1e-6

@@ -44,7 +44,9 @@ def test_oracle_embedding_matches_reference_gaussianfft(oracle32):
     import torch
     e_t = torch.sin(torch.matmul(torch.tensor(pts), torch.tensor(B))).numpy()
     assert np.abs(ref - e_t).max() == 0.0             # same ATen ops -> bit-identical to the reference object code
-    # the C oracle evaluates p0*B0 + p1*B1 + p2*B2 then sinf: within 1 ulp of the argument of the reference
+    # the C oracle evaluates fma(p2, B2, fma(p1, B1, p0*B0)) then sinf: the SAME argument bits as the reference object code's matmul (MKL sgemm
+    # accumulates with FMAs in k order, tests/test_oracle.py::test_aten_matmul_k3_is_an_fma_chain), so what is left is sinf against ATen's
+    # vectorised sine: 5e-7 (the unfused sum the oracle used until round 4 put the argument an ulp of |pB| ~ 1e2 away: up to 8e-6 here)
     lay0 = 3 * 93
     P2 = np.zeros_like(P)
     P2[:lay0] = P[:lay0]
@@ -71,4 +73,4 @@ def test_oracle_embedding_matches_reference_gaussianfft(oracle32):
         fw = oracle32.render_forward(op, sc["grids"], decs, "middle", ro, rd, None, want_aux=True)
         got = fw["raw"][:, 0, 3]
         # z = 0.01 -> p = o + d*0.01 = o (d ~ 0): relu(e_k)
-        assert np.abs(got - np.maximum(ref[:, k], 0)).max() < 2e-5
+        assert np.abs(got - np.maximum(ref[:, k], 0)).max() < 5e-7

@@ -335,6 +335,111 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
     return out
 
 
+def quat_cam(c2w):
+    """c2w [4,4] -> pose 7-vector (qw, qx, qy, qz, tx, ty, tz) padded to 8 floats (get_tensor_from_camera, utils.h:212-231)"""
+    R = c2w[:3, :3].astype(np.float64)
+    qw = np.sqrt(max(1e-12, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    q = np.array([qw, (R[2, 1] - R[1, 2]) / (4 * qw), (R[0, 2] - R[2, 0]) / (4 * qw), (R[1, 0] - R[0, 1]) / (4 * qw)])
+    return np.concatenate([q, c2w[:3, 3], [0.0]]).astype(np.float32)
+
+
+def run_k5_loop(local, rank, world, dist, comm, cycles=20, warmup=3, track_rays=200, track_iters=10, map_rays=1000, map_iters=12):
+    """BASELINE configs[4] as a loop: per frame of a TUM-fr1/desk-class sequence (bound / camera declared in tests/scenes.py), the Tracker's
+    iterations on 200 pixels of the new frame (config/nice_slam.yaml tracking.pixels / iters; on rank 0 only, its pose then goes to every rank: 8
+    floats), then the frame's share of the Mapper's iterations (mapping.iters 60 on every 5th frame = 12 per frame) on 1000 pixels of a
+    5-frame window in the colour stage WITH bundle adjustment (4 poses optimised, the oldest fixed: src/Mapper.cpp:305-329): rays sharded over
+    the ranks, ONE all-reduce per iteration of [marked voxels | colour decoder | loss | 40 floats of pose gradient], replicated Adam on grids,
+    decoder and poses (ShardedMapper.step_ba).  Everything an iteration needs is drawn on the device from the current poses (nsk_prepare_rays)."""
+    import nice_slam_cpp_amd as pkg
+    import nice_slam_cpp_amd.dist as nd
+    import scenes
+    dev = torch.device("cuda", local)
+    cam = scenes.CAM_TUM
+    intr = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    H, W = cam["H"], cam["W"]
+    sc = scenes.make_scene(42, scenes.grid_shapes_for(scenes.K5_BOUND), bound=scenes.K5_BOUND)
+    rng = np.random.default_rng(777)
+    nf = 5
+    c2ws = [scenes.make_camera(rng, sc["bound"], "z") for _ in range(nf)]
+    cu = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev).contiguous()
+    depth = [cu(scenes.frame_depth_image(sc["bound"], c, **cam)) for c in c2ws]
+    color = [cu(scenes.frame_color_image(sc["bound"], c, **cam)) for c in c2ws]
+    ctx = pkg.Context(local)
+    ctx.set_render_opts()
+    ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
+    for k in ("coarse", "middle", "fine", "color"):
+        ctx.frustum_mask(k, depth[-1], intr, c2ws[-1])
+    ctx.decoder_set_trainable("color", True)
+    cams = cu(np.stack([quat_cam(c) for c in c2ws]))                 # [nf, 8], replicated
+    cam_m, cam_v = torch.zeros_like(cams), torch.zeros_like(cams)
+    trk = cu(quat_cam(c2ws[-1])); trk_m, trk_v = torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+    per = map_rays // nf
+    N = per * nf
+    frames = [(f * per, per, f != 0) for f in range(nf)]
+    xt = torch.zeros(8 * nf + 8, device=dev)
+    g_ro, g_rd = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
+    tg_ro, tg_rd = torch.zeros(track_rays, 3, device=dev), torch.zeros(track_rays, 3, device=dev)
+    loss = torch.zeros(1, device=dev)
+    mapper = nd.ShardedMapper(ctx, comm=comm)
+    lr = STAGE_LR["color"]
+    edge = 20                                                        # tracking.ignore_edge_W / _H
+    seed = [1000]
+    ba_step, trk_step = [0], [0]
+
+    def cycle():
+        if rank == 0:                                                # ---- Tracker (src/Tracker.cpp:92-113) on the newest frame
+            for _ in range(track_iters):
+                seed[0] += 1
+                r = ctx.prepare_rays([dict(depth=depth[-1], color=color[-1], pose=trk[:7], seed=seed[0])], track_rays, (edge, H - edge, edge, W - edge), intr)
+                ctx.set_ray_mask(r["keep"])
+                ctx.track_step("color", r["rays_o"], r["rays_d"], r["gt_depth"], r["gt_color"], -1.0, 0.5, True, True, True, flags=4, loss=loss, g_rays=(tg_ro, tg_rd))
+                ctx.set_ray_mask(None)
+                trk_step[0] += 1
+                ctx.pose_step(r["pix_i"], r["pix_j"], intr, tg_ro, tg_rd, trk, trk_m, trk_v, 1e-3, trk_step[0])
+        if world > 1:                                                # the tracked pose to every rank (28 bytes of payload)
+            dist.broadcast(trk, src=0)
+        cams[nf - 1].copy_(trk)
+        for _ in range(map_iters):                                   # ---- Mapper, colour stage with bundle adjustment (src/Mapper.cpp:366-368,430-446)
+            seed[0] += 1
+            full = ctx.prepare_rays([dict(depth=depth[f], color=color[f], pose=cams[f, :7], seed=seed[0] * 131 + f) for f in range(nf)], per, (0, H, 0, W), intr)
+            ba_step[0] += 1
+            mapper.step_ba("color", full, frames, cams, cam_m, cam_v, intr, lr, 1e-3, ba_step[0], xt, g_ro, g_rd, w_color=0.5)
+
+    with torch.cuda.stream(ctx.tstream):
+        for _ in range(warmup):
+            cycle()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(cycles):
+            cycle()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        ctx.profile_begin()
+        cycle()
+        prof = ctx.profile_end()
+    ctx.sync()
+    out = {"workload": "configs[4]: TUM-fr1/desk-class volume (bound [[-3.5,3],[-3,3],[-3,3]], 640x480 camera; declared in the harness), per frame: Tracker %d iterations x %d "
+                       "pixels (rank 0) + pose to all ranks + Mapper %d colour-stage iterations x %d pixels over a %d-frame window with bundle adjustment (4 poses), rays "
+                       "sharded x%d" % (track_iters, track_rays, map_iters, N, nf, world),
+           "ms_per_frame": 1e3 * dt / cycles, "frames": cycles,
+           "value": map_iters * N * cycles / dt, "unit": "mapping rays/s (whole job)", "mapping_rays_per_frame": map_iters * N, "tracking_rays_per_frame": track_iters * track_rays,
+           "exchange_floats_ba": int(xt.numel()), "final_ba_loss": float(xt[8 * nf]), "kept_rays_last_iteration": float(xt[8 * nf + 1]),
+           "kernels_us_per_frame": {k: round(1e3 * ms, 1) for k, (c, ms) in prof.items()}, "launches_per_frame": int(sum(c for c, ms in prof.values())),
+           "hardware": "unmeasured on a multi-GPU node unless n_gpus > 1 in this line" if world == 1 else "%d ranks" % world}
+    ctx.close()
+    return out
+
+
 def sq_profile(kernel_prefix):
     """MFMA-busy share of the dominant kernel from the committed SQ counter passes of this same command (profiles/, tools/profile_round.sh):
     SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x the kernel's cycles); the kernel's cycles = GRBM_GUI_ACTIVE / 8 XCDs where that
@@ -568,10 +673,15 @@ def main():
                 extras[name]["value"] = kw["rays_total"] / (1e-3 * sm["ms_per_step"])
             if "matmul_mode" in kw:
                 extras[name]["forward_operands"] = {0: "fp32 MFMA (v_mfma_f32_16x16x4_f32)", 1: "three bf16 pieces (24 bits)"}[kw["matmul_mode"]]
+        # BASELINE configs[4]: the Tracker + Mapper loop with bundle adjustment (at every N: on one GPU the same code with world = 1)
+        k5 = run_k5_loop(local, rank, world, dist, comm, cycles=10 if world == 1 else 20)
         if rank == 0:
+            extras["K5_loop"] = k5
             out["extras"] = extras
     if rank != 0:
         if dist is not None:
+            if comm is not None:
+                nd.rccl_comm_destroy(comm)
             dist.destroy_process_group()
         return
     if not args.no_cpu_baseline and world == 1:
@@ -581,6 +691,8 @@ def main():
         out["cpu_baseline"] = None
     print(json.dumps(out))
     if dist is not None:
+        if comm is not None:
+            nd.rccl_comm_destroy(comm)
         dist.destroy_process_group()
 
 

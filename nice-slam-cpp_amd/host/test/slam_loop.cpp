@@ -3,8 +3,16 @@
 //   slam_loop <tum|replica|scannet> <sequence dir> <nice_slam.yaml> <cofusion.yaml> <out dir> [frames] [map every]
 // <sequence dir>/bound.txt holds the scene bound (6 numbers: x0 x1 y0 y1 z0 z1; the reference hard-codes its own).  Writes est_poses.npy,
 // gt_poses.npy [F,4,4], track_loss.npy [F] (last iteration's loss; 0 for frame 0), map_loss.npy [mapped frames].
+// On a node (BASELINE configs[4], one process per GPU): NSK_RANK / NSK_WORLD / NSK_DEVICE (= local rank) / NSK_RCCL_ID_FILE (a path every rank
+// can read; rank 0 publishes the ncclUniqueId there) in the environment of every process.  The Tracker runs on rank 0 only (200 rays: nothing
+// to shard, and its median couples all rays, src/Tracker.cpp:70); its pose goes to every rank as a sum with zeros (8 floats); the Mapper's rays
+// shard over the ranks with ONE all-reduce per iteration (Mapper::set_distributed).  Rank 0 writes the outputs.
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
+
+#include <hip/hip_runtime_api.h>
+
 #include <sstream>
 
 #include "Mapper.h"
@@ -54,6 +62,19 @@ int main(int argc, char** argv)
         Mapper mapper(ns, cf, false);
         tracker.set_bound(bound); mapper.set_bound(bound);
         tracker.seed(100); mapper.seed(200);
+        nskh::Dist dist;
+        if (const char* w = std::getenv("NSK_WORLD")) {
+            dist.world = std::atoi(w);
+            dist.rank = std::getenv("NSK_RANK") ? std::atoi(std::getenv("NSK_RANK")) : 0;
+            if (dist.world > 1) {
+                const char* idf = std::getenv("NSK_RCCL_ID_FILE");
+                if (!idf) { std::fprintf(stderr, "NSK_WORLD > 1 needs NSK_RCCL_ID_FILE\n"); return 2; }
+                dist.comm = nskh::rccl_comm_from_file(dist.rank, dist.world, idf);
+                mapper.set_distributed(dist);
+            }
+        }
+        float* d_pose = nullptr;                                              // 8 floats on the device for the pose broadcast
+        if (dist.on() && hipMalloc((void**)&d_pose, 8 * sizeof(float)) != hipSuccess) { std::fprintf(stderr, "hipMalloc failed\n"); return 1; }
         const int F = max_frames > 0 ? std::min(max_frames, reader.n_imgs) : reader.n_imgs;
         std::vector<torch::Tensor> est(F), gts(F);
         std::vector<float> tl, ml;
@@ -66,10 +87,20 @@ int main(int argc, char** argv)
             gts[i] = gt;
             if (i == 0) { est[i] = gt.clone(); tl.push_back(0.f); }          // the first pose is given (NICE-SLAM's convention)
             else {
-                tracker.run(decoders, color_t, depth_t, est[i - 1], i);       // initialised from the previous estimate
-                torch::Tensor RT = get_camera_from_tensor(tracker.last_camera_tensor);
+                torch::Tensor cam7 = torch::zeros({8});
+                if (dist.rank == 0) {
+                    tracker.run(decoders, color_t, depth_t, est[i - 1], i);   // initialised from the previous estimate
+                    cam7.index_put_({Slice(None, 7)}, tracker.last_camera_tensor);
+                }
+                if (dist.on()) {                                              // rank 0's pose to every rank
+                    if (hipMemcpy(d_pose, cam7.data_ptr<float>(), 8 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("H2D failed");
+                    dist.broadcast0(d_pose, 8);
+                    nskh::check(nsk_sync(nskh::ctx()));
+                    if (hipMemcpy(cam7.data_ptr<float>(), d_pose, 8 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("D2H failed");
+                }
+                torch::Tensor RT = get_camera_from_tensor(cam7.index({Slice(None, 7)}).contiguous());
                 est[i] = torch::cat({RT, torch::tensor({{0.f, 0.f, 0.f, 1.f}})}, 0);
-                tl.push_back(tracker.last_losses.empty() ? 0.f : tracker.last_losses.back());
+                tl.push_back(dist.rank == 0 && !tracker.last_losses.empty() ? tracker.last_losses.back() : 0.f);
             }
             for (int k = i + 1; k < F; ++k) if (!est[k].defined()) est[k] = est[i].clone();      // Mapper::run indexes the whole vector
             if (i % every == 0) {
@@ -79,9 +110,10 @@ int main(int argc, char** argv)
             std::printf("frame %d: track loss %.4f, |t_est - t_gt| %.4f m%s\n", i, tl.back(),
                         (est[i].index({Slice(None, 3), 3}) - gt.index({Slice(None, 3), 3})).norm().item<float>(), i % every == 0 ? ", mapped" : "");
             // device time of the frame's loops (stream-synchronised walls the classes keep): the Tracker's whole iteration loop, the Mapper's mean iteration
-            if (i > 0) std::printf("time frame %d: tracker loop %.1f us\n", i, tracker.last_run_us);
+            if (i > 0 && dist.rank == 0) std::printf("time frame %d: tracker loop %.1f us\n", i, tracker.last_run_us);
             if (i % every == 0) std::printf("time frame %d: mapper iteration %.1f us\n", i, mapper.last_iter_us);
         }
+        if (dist.rank != 0) { std::printf("slam_loop rank %d ok\n", dist.rank); return 0; }
         save_npy(out + "est_poses.npy", torch::stack(est)); save_npy(out + "gt_poses.npy", torch::stack(gts));
         save_npy(out + "track_loss.npy", torch::tensor(tl)); save_npy(out + "map_loss.npy", torch::tensor(ml));
         for (auto k : keys) save_npy(out + k + ".npy", c.at(k));

@@ -414,6 +414,31 @@ class Context:
                                  C.c_float(eps), int(step), _ptr(g_cam_out)))
 
     @_ordered
+    def pose_step_multi(self, first, count, active, pix_i, pix_j, intr, g_ro, g_rd, cams, m=None, v=None, lr=0.0, step=0, mode=0, b1=0.9, b2=0.999,
+                        eps=1e-8, g_cams=None, keep=None):
+        """nsk_pose_step_multi: the pose kernels of every frame of a window in one launch.  first / count / active: per-frame ray ranges of the
+        batch arrays and "this pose is optimised" flags (host lists); cams [nf, 8] cuda; step >= 1: gradient + Adam (m, v [nf, 8]);
+        step == 0: gradients only into g_cams [8 nf + 8] (the N > 1 form; g_cams[8 nf + 1] = kept rays of `keep`)"""
+        import numpy as np
+        nf = len(first)
+        f = np.ascontiguousarray(first, np.int32); c = np.ascontiguousarray(count, np.int32); a = np.ascontiguousarray(active, np.uint8)
+        fx, fy, cx, cy = intr
+        _chk(lib().nsk_pose_step_multi(self.h, nf, f.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
+                                       _ptr(pix_i), _ptr(pix_j), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), mode, _ptr(g_ro), _ptr(g_rd),
+                                       _ptr(cams), _ptr(m), _ptr(v), C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), int(step), _ptr(g_cams),
+                                       _ptr(keep), int(keep.shape[0]) if keep is not None else 0))
+
+    def set_depth_max_batch(self, gt_depth=None, keep=None):
+        """nsk_set_depth_max_batch: steps given gt_depth_max < 0 take max(gt_depth) over THIS batch (the whole batch a shard belongs to)"""
+        self._dmax = (gt_depth, keep)
+        _chk(lib().nsk_set_depth_max_batch(self.h, _ptr(gt_depth), _ptr(keep), int(gt_depth.shape[0]) if gt_depth is not None else 0))
+
+    def grad_extra(self, buf=None):
+        """nsk_grad_extra: a float32 cuda vector (multiple of 4 floats) that travels with grad_pack / grad_unpack / allreduce_grads_rccl"""
+        self._xextra = buf
+        _chk(lib().nsk_grad_extra(self.h, _ptr(buf), C.c_size_t(buf.numel() if buf is not None else 0)))
+
+    @_ordered
     def rays_backward(self, pix_i, pix_j, intr, g_ro, g_rd, mode=0):
         import torch
         g = torch.empty(3, 4, device=g_ro.device)

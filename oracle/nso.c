@@ -668,13 +668,20 @@ NSO_API int nso_preacts(const nso_opts* o, const nso_grid* grids, const real* co
  * The sources are carried through the network by the EXACT first-order map of this sample (the Jacobians d a_l / d source with this
  * sample's ReLU branches, so that paths that cancel do cancel), and only their signs are taken worst-case:
  *                                                      tau_l[o] = sum_src |d a_l[o] / d src| mag(src) + (local part of r_l[o]).
+ * geometry_err = 0 leaves out dz, dp and ds: the bound between two fp32 evaluations that form z, p and p.B with the SAME operations (the HIP
+ * kernels and the fp32 build of this file since round 4: bit-identical arguments) and differ in the sine and in the order of the sums.
+ * quadrature = 1 turns the worst-case bound into the STANDARD DEVIATION of the probabilistic rounding model (Higham & Mary 2019: rounding errors
+ * as independent zero-mean variables): every source enters with its rms (a uniform error of half-width e has rms e / sqrt 3; a sum of K rounded
+ * additions u / sqrt 3 times the root-sum-square of the running sums) and the contributions add in quadrature instead of in absolute value.  The
+ * caller multiplies by the number of sigmas it wants (6: one exceedance expected in 10^9 inputs).
+ * tau_raw0 (optional, [N*S]): the same bound for the decoder's first output (the occupancy that enters relu(sigma), utils.h:160).
  * A branch of an fp32 evaluation that differs from this (exact) evaluation's must have |a| <= tau (to first order in u);
  * tests/test_gpu_relu.py asserts it for every ReLU of the HIP forward that took the other branch.  Worst-case signs over 93 + 128 sources:
  * ~10x above the rms error, three orders below a typical |a|. */
 #define NSRC (E_DIM + 4 * H_DIM)
 NSO_API int nso_preact_bounds(const nso_opts* o, const nso_grid* grids, const real* const* P, int stage, int which, int N,
                               const real* rays_o, const real* rays_d, const real* gt_depth, real gt_depth_max, real sin_err,
-                              const unsigned char* want, real* tau_out)
+                              int geometry_err, int quadrature, const unsigned char* want, real* tau_out, real* tau_raw0)
 {
     dec_layout L[4]; for (int i = 0; i < 4; ++i) make_layout(i, &L[i]);
     if (which < 1 || which > 3) return -1;
@@ -693,23 +700,23 @@ NSO_API int nso_preact_bounds(const nso_opts* o, const nso_grid* grids, const re
         real (*Jh)[NSRC] = (real (*)[NSRC])malloc(sizeof(real) * H_DIM * NSRC);      /* d h_{l-1} / d source */
         real (*Jh2)[NSRC] = (real (*)[NSRC])malloc(sizeof(real) * H_DIM * NSRC);     /* d h_2 / d source (skip connection of block 3) */
         real (*Ja)[NSRC] = (real (*)[NSRC])malloc(sizeof(real) * H_DIM * NSRC);
-        const real dz = 8 * u * r_abs(z[S - 1]);
+        const real dz = geometry_err ? 8 * u * r_abs(z[S - 1]) : 0;
         for (int s = 0; s < S; ++s) {
             if (want && !want[(size_t)n * S + s]) continue;
             real p[3], dp[3];
             for (int k = 0; k < 3; ++k) {
                 p[k] = ro[k] + rd[k] * z[s];
-                dp[k] = r_abs(rd[k]) * dz + u * (r_abs(rd[k] * z[s]) + r_abs(p[k]));
+                dp[k] = geometry_err ? r_abs(rd[k]) * dz + u * (r_abs(rd[k] * z[s]) + r_abs(p[k])) : 0;
             }
             point_forward(o, grids, P, L, stage, p, &st);
             const dec_act* A = &st.act[which];
-            real mag[NSRC], dc[64];
+            real mag[NSRC], dc[64], loc4[H_DIM];
             const real* B = Pw + Lw->oB;
             for (int k = 0; k < E_DIM; ++k) {
                 real t0 = p[0] * B[k], t1 = p[1] * B[E_DIM + k], t2 = p[2] * B[2 * E_DIM + k];
                 real ds = r_abs(B[k]) * dp[0] + r_abs(B[E_DIM + k]) * dp[1] + r_abs(B[2 * E_DIM + k]) * dp[2] +
                           u * (r_abs(t0) + r_abs(t0 + t1) + r_abs(t0 + t1 + t2));
-                mag[k] = ds + sin_err;
+                mag[k] = quadrature ? r_sqrt((geometry_err ? ds * ds : 0) + sin_err * sin_err) * (real)0.57735 : (geometry_err ? ds : 0) + sin_err;
             }
             for (int half = 0; half < (which == 2 ? 2 : 1); ++half) {          /* fine: its own level, then the middle level (MLP.cpp:79-84) */
                 const nso_grid* g = &grids[half == 0 ? which : 1];
@@ -753,14 +760,50 @@ NSO_API int nso_preact_bounds(const nso_opts* o, const nso_grid* grids, const re
                             for (int c = 0; c < nsrc; ++c) Ja[q][c] += wk * Jh[k][c];
                         }
                     }
-                    loc = ((real)nx * u + 2 * u22) * loc + u * r_abs(b[q]);
-                    real t = loc;
-                    for (int c = 0; c < nsrc; ++c) t += r_abs(Ja[q][c]) * mag[c];
+                    if (quadrature) {                                            /* rms of K rounded terms + the pieces' 2^-22: sqrt(K) u / sqrt 3 x rss of the terms */
+                        real ss = 0;
+                        if (i == 0 || i == 3) for (int k = 0; k < E_DIM; ++k) ss += (w[k] * A->e[k]) * (w[k] * A->e[k]);
+                        if (i == 3) for (int k = 0; k < H_DIM; ++k) ss += (w[E_DIM + k] * A->h[2][k]) * (w[E_DIM + k] * A->h[2][k]);
+                        if (i != 0 && i != 3) for (int k = 0; k < H_DIM; ++k) ss += (w[k] * A->h[i - 1][k]) * (w[k] * A->h[i - 1][k]);
+                        /* K rounded additions, each of the size of the running sum (a random walk from the bias to a: mean square a^2 / 3 + ss / 2) */
+                        loc = r_sqrt((u * u / 3) * (real)nx * (A->a[i][q] * A->a[i][q] / 3 + ss / 2) + (u22 * u22 / 3) * ss);
+                    } else loc = ((real)nx * u + 2 * u22) * loc + u * r_abs(b[q]);
+                    real t = quadrature ? loc * loc : loc;
+                    for (int c = 0; c < nsrc; ++c) { const real v = r_abs(Ja[q][c]) * mag[c]; t += quadrature ? v * v : v; }
+                    if (quadrature) t = r_sqrt(t);
                     tau[i * H_DIM + q] = t;
-                    if (i < 4) {                                                 /* block output: relu(a) + fc c + bc; its local error becomes source (i, q) */
+                    {                                                            /* block output: relu(a) + fc c + bc; its local error becomes source (i, q) */
                         real flin = 0, fmag = 0;
                         for (int k = 0; k < Lw->c_dim; ++k) { flin += r_abs(Fw[(size_t)q * Lw->c_dim + k]) * dc[k]; fmag += r_abs(Fw[(size_t)q * Lw->c_dim + k] * A->c[k]); }
-                        mag[E_DIM + i * H_DIM + q] = loc + flin + ((real)Lw->c_dim * u + 2 * u22) * fmag + u * r_abs(Fb[q]) + 2 * u * r_abs(A->h[i][q]);
+                        real m = loc + flin + ((real)Lw->c_dim * u + 2 * u22) * fmag + u * r_abs(Fb[q]) + 2 * u * r_abs(A->h[i][q]);
+                        if (quadrature) {
+                            real fs = 0;
+                            for (int k = 0; k < Lw->c_dim; ++k) fs += (Fw[(size_t)q * Lw->c_dim + k] * A->c[k]) * (Fw[(size_t)q * Lw->c_dim + k] * A->c[k]);
+                            const real f1 = (r_sqrt((real)Lw->c_dim) * u + u22) * (real)0.57735 * r_sqrt(fs), f2 = u * (real)0.57735 * r_abs(A->h[i][q]);
+                            m = r_sqrt(loc * loc + flin * flin * (real)0.3333 + f1 * f1 + 2 * f2 * f2);
+                        }
+                        if (i < 4) mag[E_DIM + i * H_DIM + q] = m; else loc4[q] = m;
+                    }
+                }
+                if (i == 4 && tau_raw0) {                                        /* out[0] = bo + Wo[0] . h4 (fp32 dot product in the kernels) */
+                    const real* Wo = Pw + Lw->oWo;
+                    real t = u * r_abs(Pw[Lw->obo]), mg = 0;
+                    real col[NSRC];
+                    for (int c = 0; c < NSRC; ++c) col[c] = 0;
+                    for (int q = 0; q < H_DIM; ++q) {
+                        const int on = A->a[4][q] > 0;
+                        mg += r_abs(Wo[q] * A->h[4][q]);
+                        t += r_abs(Wo[q]) * loc4[q];
+                        if (on) for (int c = 0; c < NSRC; ++c) col[c] += Wo[q] * Ja[q][c];
+                    }
+                    if (quadrature) {
+                        real t2 = 0, m2 = 0;
+                        for (int q = 0; q < H_DIM; ++q) { t2 += (Wo[q] * loc4[q]) * (Wo[q] * loc4[q]); m2 += (Wo[q] * A->h[4][q]) * (Wo[q] * A->h[4][q]); }
+                        for (int c = 0; c < NSRC; ++c) t2 += (col[c] * mag[c]) * (col[c] * mag[c]);
+                        tau_raw0[(size_t)n * S + s] = r_sqrt(t2 + (real)H_DIM * u * u * (real)0.3333 * m2);
+                    } else {
+                    for (int c = 0; c < NSRC; ++c) t += r_abs(col[c]) * mag[c];
+                    tau_raw0[(size_t)n * S + s] = t + (real)(H_DIM + 2) * u * mg;
                     }
                 }
                 if (i < 4) {

@@ -192,9 +192,11 @@ class Oracle:
         assert rc == 0
         return a
 
-    def preact_bounds(self, opts, grids, decoders, stage, which, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0, sin_err=3.2e-7, want=None):
+    def preact_bounds(self, opts, grids, decoders, stage, which, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0, sin_err=3.2e-7, want=None, geometry_err=True,
+                      want_raw0=False, quadrature=False):
         """[N*S, 5, 32]: first-order bound on |ReLU input of an fp32 evaluation - exact| at the samples with want[N*S] set (None: all; zeros
-        elsewhere) (test aid, see nso.c nso_preact_bounds)"""
+        elsewhere) (test aid, see nso.c nso_preact_bounds).  geometry_err=False: the bound between two fp32 evaluations that share z, p and
+        p.B bit for bit.  quadrature: the standard deviation of the probabilistic rounding model instead of the worst case.  want_raw0: also return the bound [N*S] on the decoder's first output (the occupancy)"""
         ro, rd = self.arr(rays_o, (-1, 3)), self.arr(rays_d, (-1, 3))
         N = ro.shape[0]
         gd = None if gt_depth is None else self.arr(gt_depth, (N,))
@@ -203,10 +205,12 @@ class Oracle:
         da, k2 = self._decs(decoders)
         tau = np.zeros((N * S, 5, 32), self.dt)
         wt = None if want is None else np.ascontiguousarray(np.asarray(want).astype(np.uint8).reshape(N * S))
+        t0 = np.zeros(N * S, self.dt) if want_raw0 else None
         rc = self.lib.nso_preact_bounds(C.byref(opts), ga, da, _stage_id(stage), _stage_id(which), N, self._p(ro), self._p(rd),
-                                        self._p(gd), self.creal(gt_depth_max), self.creal(sin_err), self._p(wt), self._p(tau))
+                                        self._p(gd), self.creal(gt_depth_max), self.creal(sin_err), int(geometry_err), int(quadrature), self._p(wt), self._p(tau),
+                                        self._p(t0))
         assert rc == 0
-        return tau
+        return (tau, t0) if want_raw0 else tau
 
     def ray_fragility(self, opts, grids, decoders, stage, rays_o, rays_d, gt_depth=None, gt_depth_max=-1.0):
         """min |ReLU input| per ray (test aid, see nso.c)"""

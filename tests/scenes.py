@@ -123,6 +123,18 @@ def frame_depth_image(bound, c2w, H, W, fx, fy, cx, cy, shrink=0.3):
     return _ray_box_far(room, o, dirs).reshape(H, W).astype(np.float32)
 
 
+def frame_color_image(bound, c2w, H, W, fx, fy, cx, cy, shrink=0.3):
+    """colour image [H,W,3] of the same room: make_rays' smooth function of the hit point, for every pixel"""
+    room = np.asarray(bound, np.float64).copy()
+    room[:, 0] += shrink
+    room[:, 1] -= shrink
+    jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    dirs = np.stack([(ii - cx) / fx, -(jj - cy) / fy, -np.ones_like(ii, dtype=np.float64)], -1).reshape(-1, 3) @ c2w[:3, :3].T.astype(np.float64)
+    o = np.broadcast_to(c2w[:3, 3].astype(np.float64), dirs.shape)
+    hit = o + dirs * _ray_box_far(room, o, dirs)[:, None]
+    return (0.5 + 0.5 * np.sin(hit * np.array([1.3, 2.1, 0.7]) + np.array([0.0, 1.0, 2.0]))).reshape(H, W, 3).astype(np.float32)
+
+
 def make_rays(seed, n, bound, H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5, n_frames=1, zero_frac=0.05,
               shrink=0.3, edge=0, cam_seed=None, up="y"):
     """rays of n seeded pixels split over n_frames seeded cameras (Mapper.cpp:223: pixels/|window| each);

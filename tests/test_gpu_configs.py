@@ -37,7 +37,7 @@ def _mapping_steps_vs_oracle(ctx, o, sc, rays, stage, steps, w_color=0.5, masks=
     """`steps` mapping iterations (src/Mapper.cpp:430-446) on the GPU, every one of them checked against the oracle:
 
       gradients   at the parameters the GPU holds before the step, the oracle's loss and its gradients of every trained level and of
-                  the colour decoder -- ALL rays, no filtering -- within 1e-2 relative L2, and within 1e-4 or within 5x of the fp32
+                  the colour decoder -- ALL rays, no filtering -- within 1e-2 relative L2, and within 1e-4 or within 2x of the fp32
                   oracle's own distance to the fp64 oracle.  (Measured 1e-6 .. 1.3e-3: of the ~10^8 ReLU inputs of a batch a few
                   dozen lie within rounding of zero, and two fp32 evaluations put them on different sides of the kink -- see
                   tests/test_gpu_parity.py::_assert_gradients for why the HIP path has more of them than the fp32 oracle.  The
@@ -107,7 +107,7 @@ def _mapping_steps_vs_oracle(ctx, o, sc, rays, stage, steps, w_color=0.5, masks=
             assert e < 100 * TOL, "step %d: d loss / d %s off by %.2e (all %d rays)" % (step, name, e, rays["rays_o"].shape[0])
             if ref64_g is not None:
                 e64, eo = rel_l2(got_g, ref64_g), rel_l2(ref_g, ref64_g)
-                assert e < TOL or e64 < 5 * eo + TOL, "step %d: d loss / d %s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (step, name, e, e64, eo)
+                assert e < TOL or e64 < 2 * eo + TOL, "step %d: d loss / d %s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (step, name, e, e64, eo)
         # the oracle's Adam on the GPU's gradient = what nsk_adam_step must produce
         expect = {}
         for k in levels:
@@ -188,22 +188,45 @@ def _strict_case(name):
     return sc, {k: (v[3750:5000] if isinstance(v, np.ndarray) and v.shape[:1] == (10000,) else v) for k, v in rays.items()}, "color", gmax
 
 
+def nonfragile_rays(oracle32, oracle64, sc, rays, stage, gmax, sigmas=5.0):
+    """Rays on which the HIP path and the fp32 oracle must take the same branch at every kink -- by a DERIVED margin, nothing tuned.  Since round 4
+    both form z, p = o + d z and the embedding argument p.B with the same operations (bit-identical: mul_rn / the FMA chain, nsk_device.h), so
+    their ReLU inputs differ only by the sine (v_sin_f32 + reduction: 3.2e-7 absolute against glibc's 6e-8) and by the rounding of the matrix
+    products (two fp16 pieces: 2^-22 relative per product; K sums).  oracle/nso.c nso_preact_bounds carries exactly those sources through the
+    sample's own Jacobian and adds them in quadrature (`rss`, per sample and unit; measured on the GPU, tests/test_gpu_relu.py: no observed
+    difference exceeds 5 rss: the largest of 1.4e8 inputs sits at 3.6).  A ray is kept when every hidden ReLU input of every decoder of the stage, and the sigma of every in-bound sample
+    (relu(sigma), utils.h:160), lies further than `sigmas` x rss from zero in the fp32 oracle."""
+    N = rays["rays_o"].shape[0]
+    args = (rays["rays_o"], rays["rays_d"], rays["gt_depth"], gmax)
+    op32, op64 = oracle32.opts(sc["bound"]), oracle64.opts(sc["bound"])
+    keep = np.ones(N, bool)
+    sig_rss = 0.0
+    for k in LEVELS[stage]:
+        a32 = oracle32.preacts(op32, sc["grids"], sc["decoders"], stage, k, *args)
+        rss, r0 = oracle64.preact_bounds(op64, sc["grids"], sc["decoders"], stage, k, *args, sin_err=3.2e-7, geometry_err=False, quadrature=True, want_raw0=True)
+        keep &= ~(np.abs(a32) <= sigmas * rss).reshape(N, -1).any(axis=1)
+        if k != "color":
+            sig_rss = sig_rss + r0
+    fw = oracle32.render_forward(op32, sc["grids"], sc["decoders"], stage, *args, want_aux=True)
+    sg = fw["raw"][..., 3]
+    keep &= ~((np.abs(sg) <= sigmas * sig_rss.reshape(sg.shape)) & (sg != 100)).any(axis=1)
+    return keep
+
+
 @pytest.mark.parametrize("case", ["K2-color", "K3-fine", "K3-color", "K4-shard"])
 def test_gradients_strict_on_nonfragile_rays(case, oracle32, oracle64):
-    """The strict arm of the gradient contract at the full size of every BASELINE config: rays none of whose ReLU inputs lies within 2e-5
-    (K2; 1e-4 in the larger K3 / K4 rooms, see below) of zero (oracle/nso.c nso_ray_fragility, evaluated in fp64) -- there the gradient is a smooth function of the inputs and the HIP path
-    must match the fp32 oracle within 1e-4 relative L2 on every trained level and the colour decoder, NO escape clause, in both sample
-    orders.  The share of rays kept is asserted and printed.  (K3: its own bound and grids, fine and colour stages; K4: a 1250-ray shard
-    with the 10000-ray batch's depth maximum passed in.)"""
+    """The threshold arm of the gradient contract at the full size of every BASELINE config: on the rays none of whose kink inputs lies within the
+    derived rounding margin of zero (nonfragile_rays: at least half of the rays of every config) the HIP path and the fp32 oracle take the same
+    branches, the gradient is one smooth function for both, and the HIP path must match the fp32 oracle within 1e-4 relative L2 on every trained
+    level and the colour decoder, NO escape clause, in both sample orders.  (K3: its own bound and grids, fine and colour stages; K4: a 1250-ray
+    shard with the 10000-ray batch's depth maximum passed in.)  Until round 4 the threshold was a tuned constant (2e-5 at K2, 1e-4 at K3 / K4) that
+    kept 35 % / 22 % / 22 % of the rays at K3-fine / K3-colour / K4: the HIP path's sample points then differed from the oracle's in the last
+    bit, wherever the compiler had fused o + d z.  tests/test_gpu_relu.py holds the all-rays form of the same contract."""
     sc, rays, stage, gmax = _strict_case(case)
     if gmax is None:
         gmax = float(rays["gt_depth"].max())                                  # (keep the batch statistic of the full batch)
-    frag = oracle64.ray_fragility(oracle64.opts(sc["bound"]), sc["grids"], sc["decoders"], stage, rays["rays_o"], rays["rays_d"], rays["gt_depth"], gmax)
-    # how close to a kink two fp32 evaluations can disagree scales with the embedding argument: p.B reaches ~4.5 * 75 = 340 rad in the reference's
-    # room (K2: half an ulp there is 1.5e-5 rad) and ~9 * 75 = 670 rad in the K3 / K4 rooms (3e-5 rad, times the first layer's weights)
-    thr = 2e-5 if case == "K2-color" else 1e-4
-    keep = frag > thr
-    assert keep.mean() > (0.5 if case == "K2-color" else 0.15), keep.mean()
+    keep = nonfragile_rays(oracle32, oracle64, sc, rays, stage, gmax)
+    assert keep.mean() >= 0.5, keep.mean()
     sub = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == keep.shape else v) for k, v in rays.items()}
     for sort_mode in (-1, 0):
         ctx = make_ctx(sc, trainable=["color"] if stage == "color" else [])
@@ -226,11 +249,14 @@ def test_k3_all_rays_gradient_by_forward_operand_mode(oracle32, oracle64):
     """What the 16-bit operand split adds to the all-rays gradient error at K3 (colour stage, 5000 rays, nothing filtered): the same step with the
     forward's matrix products on the fp32 MFMA (nsk_set_matmul_mode 0, exact fp32 products), on three bf16 pieces (mode 1) and on two fp16
     pieces (mode 2, the default) -- the ReLU bits the backward uses come from that forward.  Every mode is measured against the fp64 oracle
-    and printed next to the fp32 oracle's own distance from it; the split forms may not be further from fp64 than 3x the fp32-MFMA form + 1e-4.
-    Measured (round 3): middle 4.77e-4 / 4.76e-4 / 4.76e-4 (fp32 oracle 4.84e-4), fine 4.58e-4 / 4.64e-4 / 4.65e-4 (4.24e-4): the kink flips
-    set the all-rays figure, whatever the operand width; colour 1.18e-4 / 3.51e-4 / 3.51e-4 (1.28e-4): the two split forms agree to the digit
-    (24 and 22 significant bits: not a precision effect) and differ from the fp32-MFMA form -- they share the forward body
-    (decode_fwd_bf16_body) and with it one set of flipped ReLUs, the fp32-MFMA body (decode_fwd_body) has another."""
+    and printed next to the fp32 oracle's own distance from it; the split forms may not be further from fp64 than 1.5x the fp32-MFMA form + 1e-5.
+    Round 3 measured colour 1.18e-4 / 3.51e-4 / 3.51e-4 (fp32 oracle 1.28e-4) and could not say why the split forms sat 3x further out.  Round 4
+    counted (tools/relu_flips.py): every body took ~130 of 38 M hidden-ReLU branches per decoder differently from the exact evaluation, as the fp32
+    oracle does; the bodies took DIFFERENT ones because hipcc had fused o + d z in one instantiation and not in the other (two instantiations of
+    the same body disagreed on as many); two rays carried 89 % of the split forms' colour error.  With the product rounding pinned (mul_rn,
+    nsk_device.h) the bodies differ on 3-7 branches and all three sit on the fp32 oracle's own figure:
+    middle 5.22e-5 / 5.11e-5 / 5.11e-5 (fp32 oracle 5.11e-5), fine 9.73e-5 / 1.16e-4 / 1.18e-4 (1.18e-4), colour 2.12e-4 / 1.95e-4 / 1.95e-4 (1.95e-4),
+    colour decoder 7.19e-5 / 6.27e-5 / 6.27e-5 (6.27e-5)."""
     sc, rays, stage, _ = _strict_case("K3-color")
     gmax = float(rays["gt_depth"].max())
     _, bw32 = _oracle_grads(oracle32, sc, sc["grids"], sc["decoders"], rays, stage, 0.5, gmax)
@@ -249,7 +275,7 @@ def test_k3_all_rays_gradient_by_forward_operand_mode(oracle32, oracle64):
     for k in names:
         print("K3 colour, all rays, d loss / d %-14s vs fp64: fp32 MFMA %.2e, 3 x bf16 %.2e, 2 x fp16 %.2e; fp32 oracle %.2e" % (k, res[0][k], res[1][k], res[2][k], eo[k]))
         for mode in (1, 2):
-            assert res[mode][k] < 3 * res[0][k] + TOL, (mode, k, res[mode][k], res[0][k])
+            assert res[mode][k] < 1.5 * res[0][k] + 0.1 * TOL, (mode, k, res[mode][k], res[0][k])
         assert res[0][k] < 100 * TOL
 
 
@@ -502,7 +528,7 @@ def test_mapping_step_on_ragged_batches(n_rays, sort_mode, oracle32, oracle64):
     pairs.append(("colour decoder", ctx.decoder_download("color", grad=True), bw["g_decoders"]["color"], bw64["g_decoders"]["color"]))
     for name, got, ref, ref64 in pairs:
         e, e64, eo = rel_l2(got, ref), rel_l2(got, ref64), rel_l2(ref, ref64)
-        assert e < TOL or e64 < 5 * eo + TOL, "%d rays, sort %d: d loss / d %s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (n_rays, sort_mode, name, e, e64, eo)
+        assert e < TOL or e64 < 2 * eo + TOL, "%d rays, sort %d: d loss / d %s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (n_rays, sort_mode, name, e, e64, eo)
     ctx.close()
 
 

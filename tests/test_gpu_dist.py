@@ -345,6 +345,71 @@ def test_map_prepare_reads_the_mask_buffer_installed_at_registration():
     assert rel_l2(out[1][1] - sc["grids"]["color"], out[0][1] - sc["grids"]["color"]) < 5e-3
 
 
+def test_sharded_ba_step_on_the_gpu_equals_the_fused_form():
+    """ShardedMapper.step_ba (nice-slam-cpp_amd/dist.py: what a rank of BASELINE configs[4] runs -- the step with ray gradients, nsk_pose_step_multi with
+    step 0 into the buffer registered with nsk_grad_extra, the packed exchange, nsk_adam_step, ONE nsk_adam_vector over every pose of the window) on
+    one rank against the single-GPU form the C++ Mapper uses (nsk_pose_step_multi with step >= 1: gradient + Adam in its launch) and against one
+    nsk_pose_step per frame: same poses, moments and pose gradients; the fixed frame does not move; the kept-ray count is the mask's."""
+    import nice_slam_cpp_amd.dist as nd
+    sc = scenes.make_scene(11, grid_std=0.05)
+    intr = (40.0, 40.0, 32.0, 24.0)
+    nf, per = 4, 50
+    rng = np.random.default_rng(3)
+    cams0 = np.zeros((nf, 8), np.float32)
+    for f in range(nf):
+        q = np.array([1.0, 0.02 * f, -0.03 * f, 0.01 * f]); q /= np.linalg.norm(q)
+        cams0[f, :4] = q; cams0[f, 4:7] = [-0.3 + 0.1 * f, 0.2, 0.1 - 0.05 * f]
+    pix_i = cu(rng.integers(4, 60, nf * per), dtype=torch.int32); pix_j = cu(rng.integers(4, 44, nf * per), dtype=torch.int32)
+    gd = cu(rng.uniform(0.8, 2.5, nf * per)); gc = cu(rng.uniform(0, 1, (nf * per, 3)))
+    frames = [(f * per, per, f != 0) for f in range(nf)]
+    res = {}
+    for form in ("sharded", "fused", "per-frame"):
+        ctx = make_ctx(sc, trainable=["color"])
+        cams = cu(cams0); m = torch.zeros_like(cams); v = torch.zeros_like(cams)
+        g_ro = torch.zeros(nf * per, 3, device="cuda"); g_rd = torch.zeros_like(g_ro)
+        xt = torch.zeros(8 * nf + 8, device="cuda")
+        loss = torch.zeros(1, device="cuda")
+        grads = []
+        with torch.cuda.stream(ctx.tstream):
+            for it in range(2):
+                ro = torch.empty(nf * per, 3, device="cuda"); rd = torch.empty_like(ro)
+                for f in range(nf):
+                    sl = slice(f * per, (f + 1) * per)
+                    ro[sl], rd[sl] = ctx.rays_from_camera(pix_i[sl], pix_j[sl], intr, cams[f, :7].contiguous())
+                keep = ctx._inside_filter_u8(ro, rd, gd)
+                full = dict(rays_o=ro, rays_d=rd, gt_depth=gd, gt_color=gc, pix_i=pix_i, pix_j=pix_j, keep=keep)
+                if form == "sharded":
+                    nd.ShardedMapper(ctx).step_ba("color", full, frames, cams, m, v, intr, LR, 1e-3, it + 1, xt, g_ro, g_rd, w_color=0.2)
+                    grads.append(xt[:8 * nf].cpu().numpy().copy())
+                    assert float(xt[8 * nf + 1]) == float(keep.sum())
+                else:
+                    ctx.set_ray_mask(keep)
+                    ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.2, True, flags=7, loss=loss, g_rays=(g_ro, g_rd))
+                    ctx.set_ray_mask(None)
+                    ctx.adam_step(LR)
+                    if form == "fused":
+                        ctx.pose_step_multi([f for f, c, a in frames], [c for f, c, a in frames], [a for f, c, a in frames], pix_i, pix_j, intr, g_ro, g_rd,
+                                            cams, m, v, lr=1e-3, step=it + 1, g_cams=xt)
+                    else:
+                        xt.zero_()
+                        for f, (first, count, active) in enumerate(frames):
+                            if active:
+                                sl = slice(first, first + count)
+                                ctx.pose_step(pix_i[sl], pix_j[sl], intr, g_ro[sl], g_rd[sl], cams[f], m[f], v[f], 1e-3, it + 1, g_cam_out=xt[8 * f:8 * f + 8])
+                    grads.append(xt[:8 * nf].cpu().numpy().copy())
+        ctx.sync()
+        res[form] = (cams.cpu().numpy(), m.cpu().numpy(), grads, ctx.grid_download("color"))
+        ctx.close()
+    for form in ("fused", "per-frame"):
+        for it in range(2):
+            assert np.abs(res["sharded"][2][it][:8]).max() == 0                                         # the window's oldest frame: no gradient
+            assert rel_l2(res["sharded"][2][it], res[form][2][it]) < 2e-4, (form, it)                   # (ray gradients are sums of atomics: order differs)
+        assert np.array_equal(res["sharded"][0][0], cams0[0]) and np.array_equal(res[form][0][0], cams0[0])
+        assert np.abs(res["sharded"][0] - res[form][0]).max() < 2e-6, form
+        assert np.abs(res["sharded"][0][1:, :7] - cams0[1:, :7]).max() > 5e-4
+        assert rel_l2(res["sharded"][3] - sc["grids"]["color"], res[form][3] - sc["grids"]["color"]) < 5e-3
+
+
 def test_rccl_communicator_bootstrapped_from_a_process_group():
     """nice-slam-cpp_amd/dist.py::rccl_comm_from_group (what bench.py does at N > 1: ncclUniqueId drawn by rank 0, its 128 bytes broadcast over the
     process group, ncclCommInitRank per rank) on a one-rank "nccl" process group: the communicator must come back and nsk_allreduce_grads over it
@@ -375,6 +440,20 @@ def test_rccl_communicator_bootstrapped_from_a_process_group():
         for k in ("middle", "fine", "color"):
             assert rel_l2(out[True][0][k], out[False][0][k]) < 1e-5
         assert rel_l2(out[True][1], out[False][1]) < 1e-5
+        # the bundle-adjustment buffer travels in the same collective (nsk_grad_extra): [8 floats per window frame | loss | kept rays | 0 x 6]
+        sc, ctx, (ro, rd, gd, gc), mk = _setup()
+        with torch.cuda.stream(ctx.tstream):
+            ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.5, True, flags=3, loss=torch.zeros(1, device="cuda"))
+            n0 = ctx.grad_pack().numel()
+            xt = torch.arange(5 * 8 + 8, dtype=torch.float32, device="cuda") * 0.25 - 3.0
+            want = xt.clone()
+            ctx.grad_extra(xt)
+            assert ctx.grad_pack().numel() == n0 + xt.numel()
+            ctx.allreduce_grads_rccl(comm)                            # one rank: the sum is the identity, through pack -> ncclAllReduce -> unpack
+            ctx.grad_extra(None)
+            ctx.adam_step(LR)
+        ctx.sync()
+        assert torch.equal(xt, want)
         rccl = _rccl()
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
@@ -385,8 +464,9 @@ def test_rccl_communicator_bootstrapped_from_a_process_group():
 def test_bench_multi_rank_line_rehearsal(tmp_path):
     """bench.py as the driver launches it at N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks on this one GPU
     over gloo (NSK_BENCH_REHEARSE=1: numbers mean nothing, the code path is the N > 1 one): the line must carry the all-reduce time alone and
-    its message size, BASELINE configs[3] as a FIXED 10000-ray batch sharded over the ranks (strong scaling), configs[1], and the headline with
-    the pipeline setting flipped."""
+    its message size, BASELINE configs[3] as a FIXED 10000-ray batch sharded over the ranks (strong scaling), configs[1], the headline with
+    the pipeline setting flipped, and BASELINE configs[4] as a loop (K5_loop: Tracker on rank 0, its pose to all ranks, sharded Mapper iterations
+    with bundle adjustment)."""
     import json
     import os
     import socket
@@ -405,7 +485,13 @@ def test_bench_multi_rank_line_rehearsal(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["rays_per_gpu"] == 600
     assert out["allreduce_us"] > 0 and out["exchange_bytes"] > 0 and out["config"]["pipeline"] is True
     ex = out["extras"]
-    assert set(ex) == {"K4_strong_10000_rays", "K2_color", "K3_pipeline_off"}
+    assert set(ex) == {"K4_strong_10000_rays", "K2_color", "K3_pipeline_off", "K5_loop"}
     assert ex["K4_strong_10000_rays"]["scaling"] == "strong" and ex["K4_strong_10000_rays"]["rays_per_gpu"] == 5000
     for k in ex:
-        assert ex[k]["allreduce_us"] > 0 and ex[k]["value"] > 0
+        if k != "K5_loop":
+            assert ex[k]["allreduce_us"] > 0 and ex[k]["value"] > 0
+    # BASELINE configs[4]: the Tracker (rank 0) + pose broadcast + sharded Mapper iterations with bundle adjustment, one exchange each
+    k5 = ex["K5_loop"]
+    assert k5["value"] > 0 and k5["ms_per_frame"] > 0 and np.isfinite(k5["final_ba_loss"]) and k5["final_ba_loss"] > 0
+    assert k5["exchange_floats_ba"] == 48 and 0 < k5["kept_rays_last_iteration"] <= 1000
+    assert "pose_multi" in k5["kernels_us_per_frame"] and "decode_bwd_multi" in k5["kernels_us_per_frame"]

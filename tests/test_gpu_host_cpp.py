@@ -528,3 +528,50 @@ def test_slam_loop_at_the_reference_config_sizes(tmp_path, capsys):
     for k in ("grid_middle", "grid_fine", "grid_color"):
         g = np.load(out / (k + ".npy"))
         assert np.isfinite(g).all() and np.abs(g).max() > 0.02
+
+
+def test_sharded_mapper_with_bundle_adjustment_equals_the_single_process_run(tmp_path):
+    """BASELINE configs[4] at N > 1 through the C++ class (Mapper::set_distributed, SURVEY.md section 8e): six frames of Mapper::run, every one a
+    keyframe, the sixth with bundle adjustment, with the window's rays sharded over THREE ranks -- one process per rank as on a node, all three
+    on this box's one GPU, the exchange a rank-ordered sum through shared memory (RCCL refuses several ranks on one device; the RCCL form of the
+    same call is nsk_allreduce_grads, tests/test_gpu_dist.py).  203 pixels per iteration: the shards are uneven and window frames split across
+    ranks.  Every rank draws the whole batch (the pixel draw is a hash of the seed), renders its contiguous shard with the batch's max(gt_depth)
+    taken over the whole batch on the device (nsk_set_depth_max_batch), and ONE exchange per iteration carries the marked voxels' gradients, the
+    colour decoder's, the loss and -- in the BA iterations -- 8 floats of pose gradient per window frame (nsk_grad_extra); grids, decoder and poses
+    then take the same Adam steps on every rank.  Checked: the ranks end bit-identical; their losses, bundle-adjustment pose gradients, poses and
+    parameters equal the single-process run's up to the order of the sums; the shards' kept rays add up to the batch's."""
+    exe = os.path.join(ROOT, "nice-slam-cpp_amd", "host", "dist_test")
+    if not os.path.exists(exe):
+        pytest.fail("dist_test is not built (run __graft_entry__.build())")
+    d = str(tmp_path)
+    r = subprocess.run([exe, d, "0", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    single = {f[3:-4]: np.load(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("r0_")}
+    world = 3
+    d2 = os.path.join(d, "w3"); os.makedirs(d2)
+    shm = "/dev/shm/nsk_dist_test_%d" % os.getpid()
+    with open(shm, "wb") as f:
+        f.truncate(4096 + world * (4 << 20) * 4)
+    try:
+        procs = [subprocess.Popen([exe, d2, str(k), str(world), shm], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in range(world)]
+        outs = [p.communicate(timeout=400)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    finally:
+        os.remove(shm)
+    ranks = [{f[3:-4]: np.load(os.path.join(d2, f)) for f in os.listdir(d2) if f.startswith("r%d_" % k)} for k in range(world)]
+    for k in range(1, world):                                    # replicas stay in step without any broadcast
+        for name in ranks[0]:
+            assert np.array_equal(ranks[0][name], ranks[k][name]), (k, name)
+    got = ranks[0]
+    assert np.allclose(got["losses"], single["losses"], rtol=2e-5, atol=1e-6), (got["losses"], single["losses"])
+    assert got["kept"][0] > 0 and single["ba_grad"].shape == got["ba_grad"].shape
+    # bundle-adjustment pose gradients: sums of the same ray gradients in another order
+    assert rel_l2(got["ba_grad"], single["ba_grad"]) < 1e-3, (got["ba_grad"], single["ba_grad"])
+    assert np.abs(got["poses"] - single["poses"]).max() < 1e-5 and np.abs(got["kf_poses"] - single["kf_poses"]).max() < 1e-5
+    assert np.abs(got["kf_poses"] - got["kf_poses"][:1]).max() > 0                      # (the poses are not all one pose: BA moved some)
+    for name in ("grid_middle", "grid_fine", "grid_color", "dec_color"):
+        far = np.abs(got[name] - single[name]) > 2e-3                                      # an Adam step on a rounding-sized gradient goes either way
+        assert far.mean() < 1e-2, (name, far.mean())
+        assert rel_l2(got[name][~far], single[name][~far]) < 2e-3, name
+    print("sharded Mapper, 3 ranks: losses within %.1e of the single-process run, BA pose gradients %.1e, poses %.1e; kept rays of the last BA iteration %d" % (
+        np.abs(got["losses"] - single["losses"]).max(), rel_l2(got["ba_grad"], single["ba_grad"]), np.abs(got["poses"] - single["poses"]).max(), int(got["kept"][0])))

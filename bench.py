@@ -202,7 +202,7 @@ TUNE = []
 
 
 def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, frustum=True, matmul_mode=None, pipeline=False,
-                 comm=None, rays_total=None, repeats=1):
+                 comm=None, rays_total=None, repeats=1, backward_mode=None):
     """time `steps` mapping iterations of workload `wl` at `N` rays per GPU (rays_total: a FIXED batch of that many rays sharded over
     the ranks instead -- strong scaling); returns dict(dt, prof, loss, scene, pool, ...).  comm: an RCCL communicator for the C-ABI
     exchange (nsk_allreduce_grads), None = torch.distributed on the packed buffer"""
@@ -233,6 +233,8 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
     ctx.set_render_opts()                                        # 32 + 16 samples (src/Renderer.cpp:9-10)
     if matmul_mode is not None:
         ctx.set_matmul_mode(matmul_mode)
+    if backward_mode is not None:
+        ctx.set_backward_mode(backward_mode)
     ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
     mask_frac = None
     if frustum:                                                  # mapping.frustum_feature_selection: True (nice_slam.yaml:62): the optimiser
@@ -365,6 +367,9 @@ def run_k5_loop(local, rank, world, dist, comm, cycles=20, warmup=3, track_rays=
     depth = [cu(scenes.frame_depth_image(sc["bound"], c, **cam)) for c in c2ws]
     color = [cu(scenes.frame_color_image(sc["bound"], c, **cam)) for c in c2ws]
     ctx = pkg.Context(local)
+    for kv in TUNE:
+        k, v = kv.split("=")
+        ctx.set_sort_mode(int(v)) if k == "sort_mode" else ctx.set_tuning(k, int(v))
     ctx.set_render_opts()
     ctx.load_scene(sc["bound"], sc["grids"], sc["decoders"])
     for k in ("coarse", "middle", "fine", "color"):
@@ -562,6 +567,7 @@ def main():
     ap.add_argument("--torch-exchange", action="store_true", help="N > 1: all-reduce the packed buffer through torch.distributed instead of nsk_allreduce_grads")
     ap.add_argument("--tune", action="append", default=[], help="key=value for nsk_set_tuning (experiments), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of each CPU baseline's timed sample")
+    ap.add_argument("--k5-only", action="store_true", help="experiments: only the K5_loop extra (BASELINE configs[4] as a loop), printed as its own JSON line")
     args = ap.parse_args()
     TUNE[:] = args.tune
 
@@ -591,6 +597,13 @@ def main():
             if comm is not None:
                 exchange = "nsk_allreduce_grads (pack -> ncclAllReduce -> unpack on the context's stream; RCCL communicator bootstrapped from the process group)"
     pipeline = True if args.pipeline < 0 else bool(args.pipeline)
+    if args.k5_only:
+        k5 = run_k5_loop(local, rank, world, dist, comm, cycles=20)
+        if rank == 0:
+            print(json.dumps(k5))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     W = workloads()
     wl = W[args.workload]
@@ -650,6 +663,7 @@ def main():
                      ("K4_shard_color", "K4", "color", dict(N=W["K4"]["rays"]), 300),
                      ("K3_color_mode0", "K3", "color", dict(N=W["K3"]["rays"], matmul_mode=0), 100),
                      ("K3_color_mode1", "K3", "color", dict(N=W["K3"]["rays"], matmul_mode=1), 100),
+                     ("K3_color_backward_fp32", "K3", "color", dict(N=W["K3"]["rays"], backward_mode=0), 100),
                      ("K3_color_no_mask", "K3", "color", dict(N=W["K3"]["rays"], frustum=False), 100),
                      ("K3_pipeline_%s" % ("off" if pipeline else "on"), "K3", "color", dict(N=W["K3"]["rays"], pipeline=not pipeline), 200)]
         else:
@@ -671,6 +685,8 @@ def main():
                 extras[name]["scaling"] = "strong"
                 extras[name]["rays_total"] = kw["rays_total"]
                 extras[name]["value"] = kw["rays_total"] / (1e-3 * sm["ms_per_step"])
+            if "backward_mode" in kw:
+                extras[name]["backward_chains"] = "fp32 MFMA (v_mfma_f32_16x16x4_f32) in every role: nsk_set_backward_mode(0), a measuring stick"
             if "matmul_mode" in kw:
                 extras[name]["forward_operands"] = {0: "fp32 MFMA (v_mfma_f32_16x16x4_f32)", 1: "three bf16 pieces (24 bits)"}[kw["matmul_mode"]]
         # BASELINE configs[4]: the Tracker + Mapper loop with bundle adjustment (at every N: on one GPU the same code with world = 1)

@@ -76,6 +76,12 @@ void* nsk_stream(nsk_ctx* ctx);                     /* the hipStream_t in use */
  * Changing the mode rebuilds the forward images of the loaded decoders and invalidates captured graphs.
  * The library reads no environment variables: this call and nsk_set_render_opts are the only behaviour switches. */
 int nsk_set_matmul_mode(nsk_ctx* ctx, int mode);
+/* The same choice for the BACKWARD's gradient chains (g_h -> W^T, fc^T products of every decoder of the stage): 2 (default) = two fp16 pieces
+ * on a per-sample power-of-two multiple of the upstream gradient; 0 = the fp32 MFMA (full-width operands: what the reference's fp32 autograd
+ * multiplies, src/Mapper.cpp:443-444) for the frozen AND the trainable roles -- a measuring stick for the gradient error and the step time of
+ * full-width arithmetic (tests/test_gpu_configs.py, bench.py extras), 1.5-2x slower.  The trainable decoder's weight-gradient panels keep two
+ * bf16 pieces (16 significant bits, fp32 sums over the samples) in both modes. */
+int nsk_set_backward_mode(nsk_ctx* ctx, int mode);
 
 /* Order in which the decoder kernels of a step walk the rays' samples (results differ only by the order of floating-point sums in the
  * gradients): -1 = automatic (DEFAULT: cell-sorted for steps that scatter into the grids without ray gradients and have >= 14336 samples -- about
@@ -291,8 +297,8 @@ int nsk_set_ray_mask(nsk_ctx* ctx, const uint8_t* d_keep);
  * (src/Renderer.cpp:76,93).  Every rank can hold the whole batch's ground-truth depths and keep bytes (they come from the same pixel draw:
  * nsk_prepare_rays of the full window is one small launch), so no collective is needed: with a depth-max batch installed
  * (d_gt_depth[n], d_keep[n] or NULL; n = 0 removes it) every step that is given gt_depth_max < 0 takes the maximum over THAT array
- * -- one extra single-block launch in front of the sampling -- instead of over its own rays.  nsk_map_prepare remembers the batch
- * installed at registration, like the ray mask. */
+ * instead of over its own rays (inside the sampling launch, every wave for itself, while that batch has at most 8192 rays; one extra
+ * single-block launch in front of the sampling beyond that).  nsk_map_prepare remembers the batch installed at registration, like the ray mask. */
 int nsk_set_depth_max_batch(nsk_ctx* ctx, const float* d_gt_depth, const uint8_t* d_keep, int n);
 /* plain Adam on a caller-owned vector (camera 7-vectors: src/Tracker.cpp:103, src/Mapper.cpp:305-329) */
 int nsk_adam_vector(nsk_ctx* ctx, int n, float* d_p, const float* d_g, float* d_m, float* d_v, float lr, float beta1,

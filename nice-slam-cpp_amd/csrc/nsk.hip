@@ -818,6 +818,7 @@ struct nsk_ctx {
     int tune_no_piggyback = 0;              // 1: a prepared batch is sampled by launches of its own at the start of its step (experiments, tests)
     int pend_w = -1, pend_nb = 0;           // decoder whose per-workgroup gradient slabs are not yet summed into the slab (flush_pending)
     int dbg_M = 0, dbg_S = 0;               // sample count / samples per ray of the last forward_core (nsk_debug_relu_bits, nsk_debug_preact)
+    int bwd_mode = 2;                       // decoder backward chains: 2 fp16 2-piece split (default), 0 fp32 MFMA (nsk_set_backward_mode: a measuring stick)
     int matmul_mode = 2;                    // decoder forward: 0 fp32 MFMA, 1 bf16 3-piece split, 2 fp16 2-piece split (nsk_bf16.h)
     double last_bytes = 0, last_flops = 0; int last_samples = 0;
     // optional per-kernel timing with HIP events on the context's stream (nsk_profile_begin / _end)
@@ -932,6 +933,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8, 2>, 160 * 1024));
     CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024 - 256)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));      // (<false>, frozen: the scan role keeps a few words of static LDS)
     CHK(set_lds(k_decode_bwd_frozen<false>, 160 * 1024 - 256));
+    CHK(set_lds(k_decode_bwd_multi_full<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi_full<true>, 160 * 1024));
     CHK(set_lds(k_decode_fwd_dump<0>, 160 * 1024)); CHK(set_lds(k_decode_fwd_dump<1>, 160 * 1024)); CHK(set_lds(k_decode_fwd_dump<2>, 160 * 1024));
     *out = c;
     return 0;
@@ -996,6 +998,14 @@ extern "C" int nsk_set_matmul_mode(nsk_ctx* c, int mode)
         for (int w = 1; w < 4; ++w) if (c->dec[w].loaded && c->dec[w].fimg16) CHK(repack16(c, w));
         invalidate_graphs(c);
     }
+    return 0;
+}
+
+extern "C" int nsk_set_backward_mode(nsk_ctx* c, int mode)
+{
+    if (!c) return fail("null ctx");
+    if (mode != 0 && mode != 2) return fail("nsk_set_backward_mode: 0 (fp32 MFMA chains) or 2 (two fp16 pieces, default)");
+    c->bwd_mode = mode;
     return 0;
 }
 
@@ -1713,7 +1723,7 @@ static int stage_key_level(int stage)
     return key_level;
 }
 static void samp_args(nsk_ctx* c, SampArgs& A, const RParams& R, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax,
-                      const float* gmax_dev, const uint8_t* mask, bool sorted, float* z, int* skey, int* srank)
+                      const float* gmax_dev, const uint8_t* mask, bool sorted, float* z, int* skey, int* srank, const nsk_ctx::DMax& dm)
 {
     const GridState& KG = c->grid[stage_key_level(stage)];
     const GridState* PG = stage >= 2 ? &c->grid[1] : nullptr;      // parent level whose cells order the samples inside a key cell (k_sample)
@@ -1722,6 +1732,7 @@ static void samp_args(nsk_ctx* c, SampArgs& A, const RParams& R, int stage, int 
     A.R = R; A.N = N; A.S = S; A.rays_o = ro; A.rays_d = rd; A.gt_depth = gt; A.gtmax_host = gtmax; A.gtmax_dev = gmax_dev; A.keep = mask; A.z_out = z;
     A.kX = KG.X; A.kY = KG.Y; A.kZ = KG.Z; A.pX = PG ? PG->X : 0; A.pY = PG ? PG->Y : 0; A.pZ = PG ? PG->Z : 0; A.ncell2 = (int)((bins / 8 + 1) / 2);
     A.skey = sorted ? skey : nullptr; A.srank = srank; A.hist = c->ws.hist;
+    if (dm.n > 0) { A.mx_gt = dm.gt; A.mx_keep = dm.keep; A.mx_n = dm.n; } else { A.mx_gt = gt; A.mx_keep = mask; A.mx_n = N; }
 }
 // halves: 256-cell chunks per workgroup (1: k_sort_scan, 2: the role inside k_decode_bwd_multi)
 static ScanArgs scan_args(nsk_ctx* c, int stage, int* offs, int halves)
@@ -1737,7 +1748,7 @@ static PlaceArgs place_args(int M, const int* skey, const int* srank, const int*
     return A;
 }
 // the batch maximum of gt_depth has to come from a launch of its own (k_sample's waves take it themselves for smaller batches)
-static bool needs_depth_max(const float* gt, float gtmax, int N, const nsk_ctx::DMax& dm) { return gt && gtmax < 0.f && (N > 8192 || dm.n > 0); }
+static bool needs_depth_max(const float* gt, float gtmax, int N, const nsk_ctx::DMax& dm) { return gt && gtmax < 0.f && (dm.n > 0 ? dm.n : N) > 8192; }
 
 // sampling (+ cell sort) of one batch into the given output set by launches of its own; `done`: stages that have already run (nsk_ctx::Prep)
 static int launch_sampling(nsk_ctx* c, const RParams& R, int stage, int N, int S, const float* ro, const float* rd, const float* gt, float gtmax,
@@ -1755,7 +1766,7 @@ static int launch_sampling(nsk_ctx* c, const RParams& R, int stage, int N, int S
         }
         ProfScope ps(c, "sample");
         SampArgs A;
-        samp_args(c, A, R, stage, N, S, ro, rd, gt, gtmax, gmax_dev, mask, sorted, z, skey, srank);
+        samp_args(c, A, R, stage, N, S, ro, rd, gt, gtmax, gmax_dev, mask, sorted, z, skey, srank, dm);
         k_sample<<<(N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS, 64 * NSK_SAMPLE_RAYS, 0, st>>>(A);
     }
     if (sorted && (done & 6) != 6) {
@@ -1958,7 +1969,8 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
     MA.n = n;
     // no trainable role and no ray gradients (the fine / middle / coarse stages of the Mapper): the 16-wave frozen kernel (nsk_device.h); with ray
     // gradients the frozen bodies need 160 VGPRs (the Tracker: 600 tiles, latency-bound either way) and stay in k_decode_bwd_multi
-    const bool frozen_only = train_role == -1 && !rays && !c->tune_no_frozen_kernel;
+    const bool full = c->bwd_mode == 0;                 // every chain on the fp32 MFMA: k_decode_bwd_multi_full, nothing rides
+    const bool frozen_only = train_role == -1 && !rays && !c->tune_no_frozen_kernel && !full;
     if (train_role >= 0 && n > 1) split_wgs_train(c->num_cu, (M + 15) / 16, n, cost, train_role, MA.wg_end);
     else split_wgs_balanced(c->num_cu, (M + 15) / 16, n, cost, MA.wg_end, frozen_only ? NSK_FROZEN_NW : 8);
     const int extra = d_loss ? 1 : 0;          // one more workgroup sums the per-ray losses written by k_composite
@@ -1967,7 +1979,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
     int scan_wgs = 0;
     {
         nsk_ctx::Prep& P = c->prep;
-        if (P.valid && P.sorted && (P.done & 3) == 1 && !rays && !c->capturing && !c->tune_no_piggyback) {
+        if (P.valid && P.sorted && (P.done & 3) == 1 && !rays && !full && !c->capturing && !c->tune_no_piggyback) {
             MA.scan = scan_args(c, P.stage, c->ws.offs_alt, frozen_only ? NSK_FROZEN_NW / 4 : 2);
             scan_wgs = MA.scan.nblocks;
             P.done |= 2;
@@ -1975,7 +1987,15 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
     }
     {
         ProfScope ps(c, "decode_bwd_multi");
-        if (frozen_only) {
+        if (full) {
+            size_t ldsf = 0;
+            for (int r = 0; r < n; ++r) {
+                const int w = MA.which[r];
+                ldsf = std::max(ldsf, MA.train[r] ? (bwd_img_floats(w) + PN_FLOATS(2)) * 4 : bwd_img_floats(w) * 4 + 8 * 3840);
+            }
+            if (rays) k_decode_bwd_multi_full<true><<<MA.wg_end[n - 1] + extra, 512, ldsf, c->stream>>>(MA);
+            else k_decode_bwd_multi_full<false><<<MA.wg_end[n - 1] + extra, 512, ldsf, c->stream>>>(MA);
+        } else if (frozen_only) {
             const size_t lds16 = lds - 8 * 3840 + (size_t)NSK_FROZEN_NW * 3840;      // image + one scatter scratch per wave
             k_decode_bwd_frozen<false><<<MA.wg_end[n - 1] + scan_wgs + extra, 64 * NSK_FROZEN_NW, lds16, c->stream>>>(MA);
         } else if (rays) k_decode_bwd_multi<true><<<MA.wg_end[n - 1] + extra, 512, lds, c->stream>>>(MA);
@@ -2085,7 +2105,7 @@ extern "C" int nsk_map_step(nsk_ctx* c, int stage, int N, const float* ro, const
     if (ride) {          // the next batch's sampling behind this batch's compositing, one launch (k_composite_sample)
         nsk_ctx::Prep& P = c->prep;
         SampArgs SA;
-        samp_args(c, SA, P.R, P.stage, P.N, P.S, P.ro, P.rd, P.gt, P.gtmax, nullptr, P.mask, P.sorted, c->ws.z_alt, c->ws.skey_alt, c->ws.srank_alt);
+        samp_args(c, SA, P.R, P.stage, P.N, P.S, P.ro, P.rd, P.gt, P.gtmax, nullptr, P.mask, P.sorted, c->ws.z_alt, c->ws.skey_alt, c->ws.srank_alt, P.dmax);
         const int cb = (N + 7) / 8, sb = (P.N + NSK_SAMPLE_RAYS - 1) / NSK_SAMPLE_RAYS;
         { ProfScope ps(c, "composite"); k_composite_sample<<<cb + sb, 512, 0, c->stream>>>(A, SA, cb); }
         P.done |= 1;

@@ -231,10 +231,10 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
         mlp_output<OD>(imgf + I::P_WO, imgf + I::P_BO, g, C.h[4], out);
         if (slot < A.M) {
             if (g == 0) {
-                if constexpr (OD == 4) *reinterpret_cast<f4*>(A.out + (size_t)m_cur * 4) = (f4){out[0], out[1], out[2], out[OD - 1]};
-                else A.out[m_cur] = out[0];
+                if constexpr (OD == 4) *reinterpret_cast<f4*>(A.out + (unsigned)m_cur * 4u) = (f4){out[0], out[1], out[2], out[OD - 1]};
+                else A.out[(unsigned)m_cur] = out[0];
             }
-            if (A.masks) A.masks[(size_t)slot * 4 + g] = C.mask;
+            if (A.masks) A.masks[(unsigned)slot * 4u + (unsigned)g] = C.mask;
         }
         if (A.hsave) save_h(A.hsave, task, lane, C.h);
     }

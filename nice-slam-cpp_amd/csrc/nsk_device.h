@@ -175,6 +175,7 @@ struct SampArgs {
     RParams R; int N, S;
     const float* rays_o; const float* rays_d; const float* gt_depth; float gtmax_host; const float* gtmax_dev; const uint8_t* keep;
     float* z_out; int kX, kY, kZ, pX, pY, pZ, ncell2; int* skey; int* srank; int* hist;
+    const float* mx_gt; const uint8_t* mx_keep; int mx_n;      // what the batch maximum of gt_depth runs over: the call's own rays, or the whole batch a shard belongs to (nsk_set_depth_max_batch)
 };
 // (a body, so that the sampling of the NEXT batch can ride in the composite launch of the current step: k_composite_sample, nsk_map_prepare)
 __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
@@ -201,15 +202,16 @@ __device__ __forceinline__ void sample_body(const SampArgs& P, int bid)
     if (has_gt && !gtmax_dev && gtmax_host < 0.f) {         // batch maximum computed by every wave itself (small batches: one launch fewer)
         // (four independent (depth, keep) load pairs per round: written as `if (keep[i]) mx = max(mx, gt[i])` the loop was two dependent
         // L2 round trips per 64 rays -- half of this kernel's 19 us at 5000 rays)
-        const float mx0 = keep ? 0.f : -NSK_INF;            // (see k_depth_max)
+        const float* __restrict__ mgt = P.mx_gt; const uint8_t* __restrict__ mkeep = P.mx_keep; const int MN = P.mx_n;
+        const float mx0 = mkeep ? 0.f : -NSK_INF;           // (see k_depth_max)
         float mx = mx0;
-        for (int i0 = 0; i0 < N; i0 += 256) {
+        for (int i0 = 0; i0 < MN; i0 += 256) {
             float v[4]; uint8_t kp[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + 64 * u + lane, N - 1);          // (clamped: a repeated element does not change a maximum)
-                v[u] = gt_depth[i];
-                kp[u] = keep ? keep[i] : (uint8_t)1;
+                const int i = min(i0 + 64 * u + lane, MN - 1);         // (clamped: a repeated element does not change a maximum)
+                v[u] = mgt[i];
+                kp[u] = mkeep ? mkeep[i] : (uint8_t)1;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) mx = fmaxf(mx, kp[u] ? v[u] : mx0);
@@ -419,13 +421,22 @@ __device__ __forceinline__ void tri_setup(const GridD& G, const float* bound, fl
     }
 }
 
+// address of channels 4g.. of voxel `vox`: the level's base pointer is wave-uniform (kernel argument) and the byte offset fits 32 bits (the host keeps
+// a level below 2^25 voxels: nsk_grid_upload), so the load can take the scalar base + 32-bit vector offset form instead of a 64-bit vector address
+// (a shift, a 64-bit add and a carry chain per corner: ~6 % of the forward's vector instructions were 64-bit address arithmetic)
+__device__ __forceinline__ const f4* voxel_ptr(const GridD& G, int vox, int g)
+{
+    const unsigned off = ((unsigned)vox * 32u + 4u * (unsigned)g) * 4u;
+    return reinterpret_cast<const f4*>(reinterpret_cast<const char*>(G.v) + off);
+}
+
 // gather the 8 channels {4g..4g+3, 16+4g..16+4g+3} of this lane's quarter into two D-layout quads
 __device__ __forceinline__ void tri_gather(const GridD& G, const Tri& T, int g, f4& c0, f4& c1)
 {
     c0 = (f4)(0.f); c1 = (f4)(0.f);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const f4* vp = reinterpret_cast<const f4*>(G.v + (size_t)T.vox[c] * 32 + 4 * g);
+        const f4* vp = voxel_ptr(G, T.vox[c], g);
         f4 a = vp[0], b = vp[4];
         c0 += T.w[c] * a; c1 += T.w[c] * b;
     }
@@ -478,15 +489,35 @@ __device__ __forceinline__ void mac_block(const Frag3& a0, const Frag3& a1, cons
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define NSK_H16_SCALE 2048.f
 struct H2 { h8 h, l; };
+// Two values at a time: h pair by v_cvt_pk_f16_f32 (round to nearest even); the residual x - h straight from the packed half by v_fma_mix_f32
+// (the fp16 operand is widened inside the instruction: exact, as the separate v_cvt_f32_f16 + v_sub_f32 were) and 2048 (x - h) rounded into
+// the low / high half of the l pair by v_fma_mixlo_f16 / v_fma_mixhi_f16 (one rounding to nearest even, as v_mul_f32 by a power of two +
+// v_cvt_pk_f16_f32 were): 2.5 vector instructions per value instead of 4, the same bits (tools/ab_outputs.py).  hipcc does not form these
+// from C (it emits cvt / sub / mul / cvt); inline asm is opaque to its hazard recogniser, hence the explicit s_nop behind the last writer:
+// a vector-ALU result needs two wait states before a matrix instruction may read it.
+__device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned& hp, unsigned& lp)
+{
+    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+    typedef float ff2 __attribute__((ext_vector_type(2)));
+    hp = __builtin_bit_cast(unsigned, __builtin_convertvector((ff2){x0, x1}, hh2));
+    float t0, t1;
+    const float k2048 = NSK_H16_SCALE;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(hp), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(hp), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(lp) : "v"(t0), "s"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(lp) : "v"(t1), "s"(k2048));
+}
 __device__ __forceinline__ H2 split_block_h(f4 q0, f4 q1)
 {
+    typedef unsigned int u4s __attribute__((ext_vector_type(4)));
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair_h(q0[0], q0[1], h0, l0);
+    split_pair_h(q0[2], q0[3], h1, l1);
+    split_pair_h(q1[0], q1[1], h2, l2);
+    split_pair_h(q1[2], q1[3], h3, l3);
+    asm volatile("s_nop 1" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
     H2 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = j < 4 ? q0[j] : q1[j - 4];
-        const _Float16 h = (_Float16)x;
-        r.h[j] = h; r.l[j] = (_Float16)((x - (float)h) * NSK_H16_SCALE);
-    }
+    r.h = __builtin_bit_cast(h8, (u4s){h0, h1, h2, h3}); r.l = __builtin_bit_cast(h8, (u4s){l0, l1, l2, l3});
     return r;
 }
 struct FragH { h8 h, l; };
@@ -574,7 +605,7 @@ __device__ __forceinline__ void tri_gather_issue(const GridD& G, const Tri& T, i
 {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const f4* vp = reinterpret_cast<const f4*>(G.v + (size_t)T.vox[c] * 32 + 4 * g);
+        const f4* vp = voxel_ptr(G, T.vox[c], g);
         R.a[c] = vp[0]; R.b[c] = vp[4];
     }
 }
@@ -850,11 +881,11 @@ __device__ __forceinline__ void sample_load(const DecArgs& A, int mm, SampleRaw&
     NSK_IDX(1, mm, A.M);
     const int n = ray_of(A, mm);     // = mm / A.S
     NSK_IDX(4, n, (A.M + A.S - 1) / A.S);
-    R.z = A.z[mm];
+    R.z = A.z[(unsigned)mm];                                     // (unsigned indices: scalar base + 32-bit vector offset addressing, no sign extension)
     // a ray's origin and direction as ONE 12-byte load each (global_load_dwordx3 needs dword alignment only): the 16 samples of a cell-sorted tile
     // come from 16 rays, so every load instruction touches 16 cache lines, and seven of them per tile and wave kept the CU's address unit busy
     // for ~2 500 cycles of a trainable iteration (tools/exp_ph3.py: the stage_a segment); three do the same work
-    const Ray3 o = *reinterpret_cast<const Ray3*>(A.rays_o + 3 * n), d = *reinterpret_cast<const Ray3*>(A.rays_d + 3 * n);
+    const Ray3 o = *reinterpret_cast<const Ray3*>(A.rays_o + 3u * (unsigned)n), d = *reinterpret_cast<const Ray3*>(A.rays_d + 3u * (unsigned)n);
     R.o[0] = o.x; R.o[1] = o.y; R.o[2] = o.z; R.d[0] = d.x; R.d[1] = d.y; R.d[2] = d.z;
 }
 __device__ __forceinline__ void sample_finish(const DecArgs& A, const SampleRaw& R, float& px, float& py, float& pz)
@@ -875,7 +906,7 @@ __device__ __forceinline__ int slot_sample(const DecArgs& A, int slot)
 #ifdef NSK_EXPERIMENT
     if (A.perm) { const int v = A.perm[s]; NSK_IDX(0, v, A.M); return v; }
 #endif
-    return A.perm ? A.perm[s] : s;
+    return A.perm ? A.perm[(unsigned)s] : s;
 }
 
 // Tile schedule shared by the decoder kernels: wave `wg` of `nw` takes blocks of 2^sh consecutive tiles, dealt round-robin over the
@@ -1384,7 +1415,7 @@ __device__ __forceinline__ void image_commit(f4* __restrict__ dst, const ImgRegs
 }
 
 // ------------------------------------------------------------------------------------------------------
-template <int WHICH, bool RAYS, int NW = 8>
+template <int WHICH, bool RAYS, int NW = 8, bool FULL = false>      // FULL: the chain on the fp32 MFMA whatever RAYS says (nsk_set_backward_mode 0)
 __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int nb)
 {
     constexpr bool XYZ = WHICH != 0;
@@ -1392,7 +1423,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     constexpr bool NEED_E = XYZ && RAYS;
     // B16: without ray gradients an MLP decoder's chain is nine K=32 products per tile; they run on the fp16 matrix cores with
     // 2-piece operands (22 significant bits, nsk_bf16.h) instead of the fp32 MFMA, which blocks the SIMD's vector issue
-    constexpr bool B16 = XYZ && !RAYS;
+    constexpr bool B16 = XYZ && !RAYS && !FULL;
     constexpr int IMG_F = B16 ? MlpBwdImgH::TOTAL_F : (XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL);
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;

@@ -273,7 +273,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // (no experiment switch removes these barriers: the scatter's run table shares LDS with the panel, and a run without them faulted the GPU)
 #define NSK_BAR() lds_barrier()
 
-template <int WHICH, bool RAYS>
+template <int WHICH, bool RAYS, bool FULL = false>      // FULL: the chain's products on the fp32 MFMA (nsk_set_backward_mode 0); the weight-gradient panels keep two bf16 pieces
 __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid, int nb)
 {
     constexpr bool XYZ = WHICH != 0;
@@ -289,7 +289,7 @@ __device__ __forceinline__ void decode_bwd_train_body(const DecArgs& A, int bid,
     // samples) because it spilled 59 VGPRs -- loop-invariant per-lane addresses, reloaded from scratch inside the loop, each reload
     // a vmcnt wait behind the previous iteration's atomics.  Without spills (opaque lane index per iteration, g_e formed after the
     // chain): 24 us, backward 270 -> 240 us at K3.
-    constexpr bool H16 = XYZ && SAVED;
+    constexpr bool H16 = XYZ && SAVED && !FULL;
     typedef MlpFwdImg<CQ> FI;
     typedef TrainPlan<WHICH> PL;
     constexpr PL plan{};
@@ -1318,4 +1318,28 @@ __global__ __launch_bounds__(512) void k_decode_bwd_multi(MultiArgs MA)
     default: decode_bwd_train_any<3, RAYS>(MA.a[r], bid, nb); break;
     }
     NSK_TS_END(1, r);
+}
+
+// The same launch with every chain on the fp32 MFMA (nsk_set_backward_mode 0: full-width operands, what the reference's fp32 autograd multiplies,
+// src/Mapper.cpp:443-444): frozen roles = the body the ray-gradient launches use, trainable role = the one-phase-per-weight body with fp32
+// fragments.  A measuring stick (tests, bench extras), not the product path: 240 fp32 MFMAs of 32 cycles per trainable tile instead of 90 of 16.
+template <bool RAYS>
+__global__ __launch_bounds__(512) void k_decode_bwd_multi_full(MultiArgs MA)
+{
+    if (MA.sum_n > 0 && blockIdx.x == gridDim.x - 1) { block_sum(MA.sum_src, MA.sum_n, MA.sum_dst); return; }
+    int r = 0;
+    while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
+    const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];
+    const int bid = blockIdx.x - b0, nb = MA.wg_end[r] - b0;
+    const int sel = MA.which[r] * 2 + (MA.train[r] ? 1 : 0);
+    switch (sel) {
+    case 0: decode_bwd_body<0, RAYS, 8, true>(MA.a[r], bid, nb); break;
+    case 1: decode_bwd_train_body<0, RAYS, true>(MA.a[r], bid, nb); break;
+    case 2: decode_bwd_body<1, RAYS, 8, true>(MA.a[r], bid, nb); break;
+    case 3: decode_bwd_train_body<1, RAYS, true>(MA.a[r], bid, nb); break;
+    case 4: decode_bwd_body<2, RAYS, 8, true>(MA.a[r], bid, nb); break;
+    case 5: break;     // (the trainable fine decoder is launched on its own: see k_decode_bwd_multi)
+    case 6: decode_bwd_body<3, RAYS, 8, true>(MA.a[r], bid, nb); break;
+    default: decode_bwd_train_body<3, RAYS, true>(MA.a[r], bid, nb); break;
+    }
 }

@@ -930,11 +930,13 @@ void Mapper::optimize_map(int num_joint_iters_, c10::Dict<std::string, torch::Te
         if (drawn_upto < joint_iter) { draw_rays(joint_iter, R); drawn_upto = joint_iter; }
         // The next iteration's batch is drawn and registered before this one is optimised, so that its sampling and cell sort ride in this
         // iteration's launches (nsk_map_prepare) -- unless its rays depend on this iteration's result (bundle adjustment moves the poses)
-        if (!sharded && joint_iter + 1 < num_joint_iters_ && !(any_ba && stage_of(joint_iter + 1) == "color")) {      // (a shard's sampling waits for the batch maximum: nothing to ride)
+        if (joint_iter + 1 < num_joint_iters_ && !(any_ba && stage_of(joint_iter + 1) == "color") && Nl > 0) {
             RayBufs& Rn = *bufs[(joint_iter + 1) & 1];
             draw_rays(joint_iter + 1, Rn); drawn_upto = joint_iter + 1;
-            check(nsk_set_ray_mask(ctx(), Rn.keep.p));
-            check(nsk_map_prepare(ctx(), nskh::stage_id(render_stage_of(joint_iter + 1)), N, Rn.ro.p, Rn.rd.p, Rn.gd.p, -1.f, NSK_GRAD_GRIDS | NSK_GRAD_DECODERS));
+            if (sharded) check(nsk_set_depth_max_batch(ctx(), Rn.gd.p, Rn.keep.p, N));          // (remembered with the registration, like the mask)
+            check(nsk_set_ray_mask(ctx(), Rn.keep.p + lo));
+            check(nsk_map_prepare(ctx(), nskh::stage_id(render_stage_of(joint_iter + 1)), Nl, Rn.ro.p + 3 * (size_t)lo, Rn.rd.p + 3 * (size_t)lo, Rn.gd.p + lo, -1.f,
+                                  NSK_GRAD_GRIDS | NSK_GRAD_DECODERS));
         }
         unsigned flags = NSK_GRAD_GRIDS | NSK_GRAD_DECODERS | (ba_now ? NSK_GRAD_RAYS : 0u);
         const std::string render_stage = render_stage_of(joint_iter);

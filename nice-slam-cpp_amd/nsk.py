@@ -24,7 +24,7 @@ SYMBOLS = (
     "nsk_camera_from_tensor", "nsk_camera_backward", "nsk_inside_filter", "nsk_adam_vector", "nsk_adam_step",
     "nsk_adam_reset", "nsk_graph_begin", "nsk_graph_end", "nsk_graph_launch", "nsk_graph_destroy", "nsk_zero_grads", "nsk_prepare_rays", "nsk_map_prepare", "nsk_grad_slab", "nsk_grad_pack", "nsk_grad_unpack", "nsk_allreduce_grads", "nsk_last_call_stats",
     "nsk_profile_begin", "nsk_profile_end", "nsk_debug_relu_bits", "nsk_debug_preact", "nsk_debug_fetch",
-    "nsk_pose_step_multi", "nsk_set_depth_max_batch", "nsk_grad_extra",
+    "nsk_pose_step_multi", "nsk_set_depth_max_batch", "nsk_grad_extra", "nsk_set_backward_mode",
 )
 
 
@@ -148,6 +148,10 @@ class Context:
         """uint8 cuda tensor [N] (or None): rays with keep == 0 take no part in the loss, its gradients and the batch statistics"""
         self._ray_mask = keep                     # keep the tensor alive while the context points at it
         _chk(lib().nsk_set_ray_mask(self.h, _ptr(keep) if keep is not None else None))
+
+    def set_backward_mode(self, mode):
+        """0: every backward chain on the fp32 MFMA (full-width operands; a measuring stick), 2 (default): two fp16 pieces"""
+        _chk(lib().nsk_set_backward_mode(self.h, int(mode)))
 
     def set_sort_mode(self, mode):
         """-1 automatic, 0 ray order, 1 cell-sorted (include/nsk.h)"""

@@ -30,7 +30,7 @@ S = 48
 SIN_ERR = 3.2e-7          # v_sin_f32 (1.25e-7 abs, tools/ubench/vsin.hip) + the two-term reduction in revolutions (1.9e-7 rad)
 
 
-def hip_step(sc, rays, stage, gmax, sort_mode=-1, matmul_mode=2):
+def hip_step(sc, rays, stage, gmax, sort_mode=-1, matmul_mode=2, backward_mode=2):
     """one mapping step on the GPU; returns gradients, the branches its forward took and what it rendered"""
     N = rays["rays_o"].shape[0]
     M = N * S
@@ -38,6 +38,7 @@ def hip_step(sc, rays, stage, gmax, sort_mode=-1, matmul_mode=2):
     ctx = make_ctx(sc, trainable=["color"] if stage == "color" else [])
     ctx.set_sort_mode(sort_mode)
     ctx.set_matmul_mode(matmul_mode)
+    ctx.set_backward_mode(backward_mode)
     loss_t = torch.zeros(1, device="cuda")
     out = (torch.zeros(N, 3, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"))
     ro, rd = cu(rays["rays_o"]), cu(rays["rays_d"])
@@ -138,3 +139,22 @@ def test_forward_bodies_agree_on_every_branch(oracle32):
             k, d01, d12, runs[0]["bits"][k].size, np.sqrt((dp.astype(np.float64) ** 2).mean()), dp.max()))
         assert d01 <= 40 and d12 <= 40, (k, d01, d12)
         assert np.sqrt((dp.astype(np.float64) ** 2).mean()) < 1e-6
+
+
+def test_backward_on_full_width_operands(oracle32):
+    """nsk_set_backward_mode(0): every gradient chain of the step on the fp32 MFMA (24-bit operands, what the reference's fp32 autograd multiplies,
+    src/Mapper.cpp:443-444) against the default (two fp16 pieces of a per-sample power-of-two multiple of the gradient: 22 bits), at K3's full
+    size, all rays, with the branches given so that only the arithmetic of the smooth part is compared: both must sit within 1e-4 of the fp32
+    oracle on every level and the colour decoder, and the printed figures are the record of what the 16-bit pieces cost in accuracy (the step
+    time of both is in bench.py's extras: K3_color_backward_fp32)."""
+    sc, rays, stage, _ = _strict_case("K3-color")
+    gmax = float(rays["gt_depth"].max())
+    errs = {}
+    for bm in (2, 0):
+        hip = hip_step(sc, rays, stage, gmax, backward_mode=bm)
+        ref = forced_oracle_grads(oracle32, sc, rays, stage, gmax, hip)
+        errs[bm] = {k: rel_l2(hip["grads"][k], ref[k]) for k in hip["grads"]}
+    for k in errs[2]:
+        print("K3 colour, all rays, branches given, d loss / d %-14s vs the fp32 oracle: chains on two fp16 pieces %.2e, on the fp32 MFMA %.2e" % (k, errs[2][k], errs[0][k]))
+        assert errs[2][k] < TOL and errs[0][k] < TOL
+        assert errs[2][k] < 3 * errs[0][k] + 5e-7, (k, errs[2][k], errs[0][k])

@@ -440,6 +440,9 @@ def run_k5_loop(local, rank, world, dist, comm, cycles=20, warmup=3, track_rays=
            "value": map_iters * N * cycles / dt, "unit": "mapping rays/s (whole job)", "mapping_rays_per_frame": map_iters * N, "tracking_rays_per_frame": track_iters * track_rays,
            "exchange_floats_ba": int(xt.numel()), "final_ba_loss": float(xt[8 * nf]), "kept_rays_last_iteration": float(xt[8 * nf + 1]),
            "kernels_us_per_frame": {k: round(1e3 * ms, 1) for k, (c, ms) in prof.items()}, "launches_per_frame": int(sum(c for c, ms in prof.values())),
+           "kernel_ms_per_frame_sum": 1e-0 * sum(ms for c, ms in prof.values()),
+           "note": "ms_per_frame is the wall time of this Python loop (about ten ctypes calls per iteration: host-bound on a slow host); kernel_ms_per_frame_sum is the "
+                   "HIP-event sum of the profiled kernels of one frame.  The C++ Mapper / Tracker are the product hosts (tests/test_gpu_host_cpp.py prints their loop times).",
            "hardware": "unmeasured on a multi-GPU node unless n_gpus > 1 in this line" if world == 1 else "%d ranks" % world}
     ctx.close()
     return out

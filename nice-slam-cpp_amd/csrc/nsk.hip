@@ -1083,6 +1083,7 @@ extern "C" int nsk_grid_upload(nsk_ctx* c, int level, const float* h, int C, int
     if (!which_ok(level)) return fail("nsk_grid_upload: bad level %d", level);
     if (C != 32) return fail("nsk_grid_upload: C must be 32 (got %d)", C);
     if (Z < 1 || Y < 1 || X < 1) return fail("nsk_grid_upload: bad shape");
+    if ((size_t)Z * Y * X >= ((size_t)1 << 25)) return fail("nsk_grid_upload: at most 2^25 - 1 voxels per level (32-bit byte offsets in the forward's gather: 128 B per voxel)");
     HIPCHK(hipSetDevice(c->device));
     GridState& G = c->grid[level];
     size_t nvox = (size_t)Z * Y * X, n = nvox * 32;
@@ -1531,7 +1532,7 @@ static int launch_decode_bwd(nsk_ctx* c, int w, int M, int S, const float* ro, c
     A.g_rays_o = g_ro; A.g_rays_d = g_rd;
     A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
     A.flags = flags;
-    if (w != 0 && (train ? w != 2 : !rays)) CHK(ensure_bimg16(c, w));      // the chains on fp16 pieces: frozen without ray gradients, trainable middle / colour
+    if (w != 0 && (!train || w != 2)) CHK(ensure_bimg16(c, w));      // the chains on fp16 pieces: every frozen MLP decoder, trainable middle / colour
     if (train && w != 2) {
         if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
         A.hsave = c->ws.hsave[w];
@@ -1942,7 +1943,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
 #else
         A.flags = flags & 0xffu;
 #endif
-        if (w != 0 && (train ? w != 2 : !rays)) CHK(ensure_bimg16(c, w));
+        if (w != 0 && (!train || w != 2)) CHK(ensure_bimg16(c, w));
         if (train && w != 2) {
             if (c->ws.hsave_M[w] != M) return fail("backward of trainable decoder %d: its forward must run with the decoder already trainable (block outputs not saved)", w);
             A.hsave = c->ws.hsave[w];

@@ -209,7 +209,7 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
         tri_setup(A.grid, A.bound, px, py, pz, T);
         Act<CQ> C;
         GatherRaw R;                                   // the gather's 16 loads are in flight while the embedding is computed
-        tri_gather_issue(A.grid, T, g, R);
+        tri_gather_issue<true>(A.grid, T, g, R);
         sample_load(A, m_next, nx);                    // unconditional (clamped): no branch, no wait here
         const int m_cur = m;
         m = m_next;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
         if constexpr (WHICH == 2) {
             Tri Tm;
             tri_setup(A.grid_mid, A.bound, px, py, pz, Tm);
-            tri_gather(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
+            tri_gather<true>(A.grid_mid, Tm, g, C.xc[CQ - 2], C.xc[CQ - 1]);
         }
         float* dump = nullptr;
         if constexpr (DUMP) dump = slot < A.M ? A.dump + (size_t)m_cur * 160 : nullptr;

@@ -424,19 +424,25 @@ __device__ __forceinline__ void tri_setup(const GridD& G, const float* bound, fl
 // address of channels 4g.. of voxel `vox`: the level's base pointer is wave-uniform (kernel argument) and the byte offset fits 32 bits (the host keeps
 // a level below 2^25 voxels: nsk_grid_upload), so the load can take the scalar base + 32-bit vector offset form instead of a 64-bit vector address
 // (a shift, a 64-bit add and a carry chain per corner: ~6 % of the forward's vector instructions were 64-bit address arithmetic)
+// O32 = false keeps the 64-bit form: in the backward bodies (at the register limit) the 32-bit form measured +2 % (K3 205.5 -> 209.8 us, two more
+// spilled registers), in the forward -2 % (140.5 -> 137.6 us), same bits either way (tools/ab_outputs.py)
+template <bool O32>
 __device__ __forceinline__ const f4* voxel_ptr(const GridD& G, int vox, int g)
 {
-    const unsigned off = ((unsigned)vox * 32u + 4u * (unsigned)g) * 4u;
-    return reinterpret_cast<const f4*>(reinterpret_cast<const char*>(G.v) + off);
+    if constexpr (O32) {
+        const unsigned off = ((unsigned)vox * 32u + 4u * (unsigned)g) * 4u;
+        return reinterpret_cast<const f4*>(reinterpret_cast<const char*>(G.v) + off);
+    } else return reinterpret_cast<const f4*>(G.v + (size_t)vox * 32 + 4 * g);
 }
 
 // gather the 8 channels {4g..4g+3, 16+4g..16+4g+3} of this lane's quarter into two D-layout quads
+template <bool O32 = false>
 __device__ __forceinline__ void tri_gather(const GridD& G, const Tri& T, int g, f4& c0, f4& c1)
 {
     c0 = (f4)(0.f); c1 = (f4)(0.f);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const f4* vp = voxel_ptr(G, T.vox[c], g);
+        const f4* vp = voxel_ptr<O32>(G, T.vox[c], g);
         f4 a = vp[0], b = vp[4];
         c0 += T.w[c] * a; c1 += T.w[c] * b;
     }
@@ -601,11 +607,12 @@ __device__ __forceinline__ float chain_scale(float (&g)[OD])
 
 // the same in two steps (loads first, weighting later) so that independent work can sit between them
 struct GatherRaw { f4 a[8], b[8]; };
+template <bool O32 = false>
 __device__ __forceinline__ void tri_gather_issue(const GridD& G, const Tri& T, int g, GatherRaw& R)
 {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const f4* vp = voxel_ptr(G, T.vox[c], g);
+        const f4* vp = voxel_ptr<O32>(G, T.vox[c], g);
         R.a[c] = vp[0]; R.b[c] = vp[4];
     }
 }
@@ -881,11 +888,11 @@ __device__ __forceinline__ void sample_load(const DecArgs& A, int mm, SampleRaw&
     NSK_IDX(1, mm, A.M);
     const int n = ray_of(A, mm);     // = mm / A.S
     NSK_IDX(4, n, (A.M + A.S - 1) / A.S);
-    R.z = A.z[(unsigned)mm];                                     // (unsigned indices: scalar base + 32-bit vector offset addressing, no sign extension)
+    R.z = A.z[mm];
     // a ray's origin and direction as ONE 12-byte load each (global_load_dwordx3 needs dword alignment only): the 16 samples of a cell-sorted tile
     // come from 16 rays, so every load instruction touches 16 cache lines, and seven of them per tile and wave kept the CU's address unit busy
     // for ~2 500 cycles of a trainable iteration (tools/exp_ph3.py: the stage_a segment); three do the same work
-    const Ray3 o = *reinterpret_cast<const Ray3*>(A.rays_o + 3u * (unsigned)n), d = *reinterpret_cast<const Ray3*>(A.rays_d + 3u * (unsigned)n);
+    const Ray3 o = *reinterpret_cast<const Ray3*>(A.rays_o + 3 * n), d = *reinterpret_cast<const Ray3*>(A.rays_d + 3 * n);
     R.o[0] = o.x; R.o[1] = o.y; R.o[2] = o.z; R.d[0] = d.x; R.d[1] = d.y; R.d[2] = d.z;
 }
 __device__ __forceinline__ void sample_finish(const DecArgs& A, const SampleRaw& R, float& px, float& py, float& pz)
@@ -906,7 +913,7 @@ __device__ __forceinline__ int slot_sample(const DecArgs& A, int slot)
 #ifdef NSK_EXPERIMENT
     if (A.perm) { const int v = A.perm[s]; NSK_IDX(0, v, A.M); return v; }
 #endif
-    return A.perm ? A.perm[(unsigned)s] : s;
+    return A.perm ? A.perm[s] : s;
 }
 
 // Tile schedule shared by the decoder kernels: wave `wg` of `nw` takes blocks of 2^sh consecutive tiles, dealt round-robin over the
@@ -1421,9 +1428,10 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     constexpr bool XYZ = WHICH != 0;
     constexpr int OD = WHICH == 3 ? 4 : 1;
     constexpr bool NEED_E = XYZ && RAYS;
-    // B16: without ray gradients an MLP decoder's chain is nine K=32 products per tile; they run on the fp16 matrix cores with
-    // 2-piece operands (22 significant bits, nsk_bf16.h) instead of the fp32 MFMA, which blocks the SIMD's vector issue
-    constexpr bool B16 = XYZ && !RAYS && !FULL;
+    // B16: an MLP decoder's chain (nine K=32 products per tile, fifteen with the embedding's g_e = W0e^T g_a0 + W3e^T g_a3 when ray gradients
+    // are wanted) runs on the fp16 matrix cores with 2-piece operands (22 significant bits, nsk_bf16.h) instead of the fp32 MFMA, which blocks
+    // the SIMD's vector issue.  Until round 4 the ray-gradient launches (the Tracker, bundle adjustment) kept the fp32 chains.
+    constexpr bool B16 = XYZ && !FULL;
     constexpr int IMG_F = B16 ? MlpBwdImgH::TOTAL_F : (XYZ ? MlpBwdImg::TOTAL : CoarseBwdImg::TOTAL);
     extern __shared__ __attribute__((aligned(16))) f4 smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -1436,7 +1444,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     const h8* img16 = reinterpret_cast<const h8*>(smem);
     const float* bimgf = reinterpret_cast<const float*>(smem);
     const float* Bm = nullptr;
-    if constexpr (XYZ && !B16) Bm = bimgf + MlpBwdImg::P_BM;
+    if constexpr (XYZ) Bm = bimgf + (B16 ? MlpBwdImgH::P_BM : MlpBwdImg::P_BM);
     const float* Wo = B16 ? bimgf + MlpBwdImgH::P_WO : (XYZ ? bimgf + MlpBwdImg::P_WO : bimgf + CoarseBwdImg::P_WO);
 
     const int ntasks = (A.M + 15) >> 4;
@@ -1520,11 +1528,17 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
                     for (int i = 0; i < 4; ++i) ga[r][i] = ((mask >> (8 * l + 4 * r + i)) & 1ull) ? gh[r][i] : 0.f;
             }
             if constexpr (B16) {
-                if (l >= 1) {
+                if (l >= 1 || NEED_E) {
                     const H2 xa = mask_block_h(xg, (unsigned)(mask >> (8 * l)) & 0xffu);      // g_a = ReLU'(.) g_h, already in pieces
-                    f4 ghn[2] = {(f4)(0.f), (f4)(0.f)}, ghl[2] = {(f4)(0.f), (f4)(0.f)};
-                    gemm_h(img16, MlpBwdImgH::WT(l > 0 ? l : 1), lane, xa, ghn, ghl);
-                    gh[0] = ghn[0] + ghl[0] * (1.f / NSK_H16_SCALE); gh[1] = ghn[1] + ghl[1] * (1.f / NSK_H16_SCALE);
+                    if constexpr (NEED_E) {                                                    // g_e (carries the sample's scale until g_p below)
+                        if (l == 3) gemm_e_h(img16, MlpBwdImgH::W3ET, lane, xa, ge);
+                        if (l == 0) gemm_e_h(img16, MlpBwdImgH::W0ET, lane, xa, ge);
+                    }
+                    if (l >= 1) {
+                        f4 ghn[2] = {(f4)(0.f), (f4)(0.f)}, ghl[2] = {(f4)(0.f), (f4)(0.f)};
+                        gemm_h(img16, MlpBwdImgH::WT(l > 0 ? l : 1), lane, xa, ghn, ghl);
+                        gh[0] = ghn[0] + ghl[0] * (1.f / NSK_H16_SCALE); gh[1] = ghn[1] + ghl[1] * (1.f / NSK_H16_SCALE);
+                    }
                 }
             } else if constexpr (XYZ) {
                 if constexpr (NEED_E) {
@@ -1565,6 +1579,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { gp[0] += ge[q][i] * b0[i]; gp[1] += ge[q][i] * b1[i]; gp[2] += ge[q][i] * b2[i]; }
                 }
+                if constexpr (B16) { gp[0] *= unscale; gp[1] *= unscale; gp[2] *= unscale; }      // the chain ran on a power-of-two multiple of the gradient
             }
             tri_grad_p(A.grid, T, g, gc, gp);
 #pragma unroll

@@ -802,6 +802,7 @@ struct nsk_ctx {
     bool median_fused_pending = false;
     int tune_no_fused_median = 0;           // 1: the Tracker's median threshold in its own launch even where the fused form applies (experiments, tests)
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
+    int tune_frozen_cost_rays = 0;          // > 0: the same for launches with ray gradients (bundle adjustment: the frozen roles also carry g_e and d/dp)
     int tune_frozen_mid_pct = 100;          // the middle decoder's frozen tile against the fine one's, in percent (its level has 8x the samples per voxel: more same-line atomics)
     int tune_no_frozen_kernel = 0;          // 1: launches without a trainable role also go through k_decode_bwd_multi (experiments, tests)
     const uint8_t* ray_mask = nullptr;      // nsk_set_ray_mask
@@ -1013,6 +1014,7 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
 {
     if (!c || !key) return fail("nsk_set_tuning: null argument");
     if (!strcmp(key, "frozen_cost")) { c->tune_frozen_cost = value; return 0; }
+    if (!strcmp(key, "frozen_cost_rays")) { c->tune_frozen_cost_rays = value; return 0; }
     if (!strcmp(key, "no_frozen_kernel")) { c->tune_no_frozen_kernel = value; return 0; }
     if (!strcmp(key, "no_piggyback")) { c->tune_no_piggyback = value; return 0; }
     if (!strcmp(key, "frozen_mid_pct")) { if (value < 10 || value > 1000) return fail("nsk_set_tuning: frozen_mid_pct out of range"); c->tune_frozen_mid_pct = value; return 0; }
@@ -1706,7 +1708,9 @@ static bool sort_pays(nsk_ctx* c, int stage, int M, unsigned flags)
 {
     if (c->deterministic) return false;          // (the cell sort's ranks come from atomics in arrival order)
     if (c->sort_mode >= 0) return c->sort_mode == 1;
-    if (!(flags & NSK_GRAD_GRIDS) || (flags & NSK_GRAD_RAYS)) return false;
+    if (!(flags & NSK_GRAD_GRIDS)) return false;             // (the Tracker: 200 rays, no scatter)
+    // Bundle adjustment (grids + rays): in cell order a tile's 16 samples belong to 16 rays, so the ray-gradient sums go lane by lane instead of
+    // one add per tile -- and the scatter still wins: per-role stamps at 1000 / 5000 rays (tools/exp_ts_ba.py) 168 -> 136 us / 742 -> 432 us.
     // Measured (tools/exp_sort_threshold.py, host_test): on the reference's grids (41 k fine cells) the two extra launches pay from ~300
     // rays x 48 on (200 rays: 92 us in ray order, 97 us sorted; 1000 rays: 236 against 162 us); on a small grid (792 cells, 9600 samples)
     // many samples share the few cells, ray order serialises their atomics and sorting wins much earlier (118 against 102 us).
@@ -1950,7 +1954,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         }
         MA.which[n] = w; MA.train[n] = train ? 1 : 0;
         // relative cost of one tile of a frozen role against one 8-tile iteration of the trainable role (= 1000)
-        const int frozen_cost = c->tune_frozen_cost > 0 ? c->tune_frozen_cost : 205;
+        const int frozen_cost = rays ? (c->tune_frozen_cost_rays > 0 ? c->tune_frozen_cost_rays : 330) : (c->tune_frozen_cost > 0 ? c->tune_frozen_cost : 205);
         cost[n] = train ? 1000 : (w == 1 ? frozen_cost * c->tune_frozen_mid_pct / 100 : frozen_cost);
         lds = std::max(lds, bwd_lds_bytes(w, train));
         if (train) train_role = (train_role == -1 && w != 2) ? n : -2;     // -2: more than one trainable decoder, or the fine one (its
@@ -2506,7 +2510,7 @@ extern "C" int nsk_prepare_rays(nsk_ctx* c, int nframes, const nsk_frame_rays* f
         A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy;
         A.pi = pi + o; A.pj = pj + o; A.gd = gd + o; A.gc = gc ? gc + 3 * o : nullptr; A.ro = ro + 3 * o; A.rd = rd + 3 * o; A.keep = keep ? keep + o : nullptr;
         A.R = c->R;
-        k_prepare_rays<<<dim3((per + 255) / 256, A.nframes), 256, 0, c->stream>>>(A);
+        { ProfScope ps(c, "prepare_rays"); k_prepare_rays<<<dim3((per + 255) / 256, A.nframes), 256, 0, c->stream>>>(A); }
         HIPCHK(hipGetLastError());
     }
     return 0;

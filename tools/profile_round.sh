@@ -1,10 +1,10 @@
 #!/bin/bash
-# Evidence for profiles/: run on the GPU box from the repo root:  bash tools/profile_round.sh r03
+# Evidence for profiles/: run on the GPU box from the repo root:  bash tools/profile_round.sh r04
 # 1. rocprofv3 --kernel-trace --stats over bench.py's default command (kernel durations; bench.py's own HIP-event figures must agree)
 # 2. separate --pmc passes, kernel-trace only, as the MI355X guide prescribes: FETCH_SIZE, WRITE_SIZE -> <tag>_pmc_hbm.json;
 #    SQ passes (MFMA instructions / busy cycles, wave cycles, LDS bank conflicts, instruction-cache misses) -> <tag>_pmc_sq.json
 set -e
-TAG=${1:-r03x}
+TAG=${1:-r04x}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -14,7 +14,7 @@ timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --outp
 # the default command, unprofiled (headline + extras + both CPU baselines)
 timeout -k 10 420 python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 cp $OUT/stats/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
-BARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-extras"
+BARGS="--steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-extras"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o pmc --output-format csv -- python3 $R/bench.py $BARGS > $OUT/pmc_$C.log 2>&1
 done

@@ -1344,6 +1344,9 @@ __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const
 #pragma unroll
     for (int t = 0; t < 4; ++t) rj[t] = __builtin_popcount(mask16 & ((2u << (4 * g + t)) - 1u)) - 1;
     float* const gcol = G.g + r16;
+    // (Round 4 tried a sample-walking form for tiles of many short runs -- the same lane mapping and atomics, the sums by six LDS reads and
+    // eight FMAs per sample of the run instead of eight fp32 MFMAs per pair of runs: K2 backward 70.1 -> 68.8 us, K4 shard 72.2 -> 73.4, K3 205.2 ->
+    // 207.0 on one box: a pass is not bound by its matrix instructions.)
     for (int p = 0; 2 * p < R; ++p) {                       // uniform: R is a wave-wide scalar
         const int want = 2 * p + (r16 >> 3);
         f4 d0 = (f4)(0.f), d1 = (f4)(0.f);

@@ -47,6 +47,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             raise NskError("libnsk.so is not built (%s); run __graft_entry__.build() -- there is no fallback path" % _LIB_PATH)
+        try:
+            import torch  # noqa: F401  -- first: torch ships its own HIP runtime; when libnsk.so is loaded before it, two runtimes end up in the process and
+        except Exception:             # nsk_ctx_create sees no device although torch.cuda does (build() followed by smoke() in one process showed it)
+            pass
         L = C.CDLL(_LIB_PATH)
         L.nsk_last_error.restype = C.c_char_p
         L.nsk_decoder_param_count.restype = C.c_size_t

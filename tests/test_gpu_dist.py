@@ -345,6 +345,47 @@ def test_map_prepare_reads_the_mask_buffer_installed_at_registration():
     assert rel_l2(out[1][1] - sc["grids"]["color"], out[0][1] - sc["grids"]["color"]) < 5e-3
 
 
+@pytest.mark.parametrize("masks", [False, True])
+def test_grad_extra_travels_with_the_packed_exchange(masks):
+    """nsk_grad_extra: the caller's vector sits behind the loss floats of the packed buffer -- with optimiser masks (marked voxels only) and without
+    (whole levels; the slab is then NOT handed out in place, which it would be without the vector) --, a sum over it comes back into the vector at
+    unpack, the grid / decoder gradients make the round trip unchanged, and removing the vector restores the old buffer.  Also the argument checks
+    of nsk_pose_step_multi."""
+    import nice_slam_cpp_amd as pkg
+    sc, ctx, (ro, rd, gd, gc), mk = _setup(masks=masks)
+    loss = torch.zeros(1, device="cuda")
+    with torch.cuda.stream(ctx.tstream):
+        ctx.map_step("color", ro, rd, gd, gc, -1.0, 0.5, True, flags=3, loss=loss)
+        g0 = {k: ctx.grid_download(k, grad=True) for k in ("middle", "fine", "color")}
+        d0 = ctx.decoder_download("color", grad=True)
+        n0 = ctx.grad_pack().numel()
+        xt = torch.arange(48, dtype=torch.float32, device="cuda") + 1.0
+        ctx.grad_extra(xt)
+        buf = ctx.grad_pack()
+        if masks:
+            assert buf.numel() == n0 + 48
+        else:                                                                # (without masks n0 was the whole slab handed out in place)
+            assert buf.numel() == sum(sc["grids"][k].size for k in ("middle", "fine", "color")) + 15900 + 4 + 48
+        assert torch.equal(buf[-48:], xt)
+        buf[-48:] *= 3.0                                                     # "the sum over three ranks"
+        ctx.grad_unpack()
+        ctx.grad_extra(None)
+        assert ctx.grad_pack().numel() == n0
+    ctx.sync()
+    assert torch.equal(xt, (torch.arange(48, dtype=torch.float32, device="cuda") + 1.0) * 3.0)
+    for k in g0:
+        assert np.array_equal(ctx.grid_download(k, grad=True), g0[k]), k
+    assert np.array_equal(ctx.decoder_download("color", grad=True), d0)
+    with pytest.raises(pkg.nsk.NskError):
+        ctx.grad_extra(torch.zeros(6, device="cuda"))                        # not a multiple of 4 floats
+    z3 = torch.zeros(4, 3, device="cuda"); pi = torch.zeros(4, dtype=torch.int32, device="cuda"); cams = torch.zeros(40, 8, device="cuda")
+    with pytest.raises(pkg.nsk.NskError):
+        ctx.pose_step_multi([0] * 40, [1] * 40, [1] * 40, pi, pi, (1.0, 1.0, 0.0, 0.0), z3, z3, cams, step=0, g_cams=torch.zeros(400, device="cuda"))   # > NSK_MAX_POSE_FRAMES
+    with pytest.raises(pkg.nsk.NskError):
+        ctx.pose_step_multi([0], [1], [1], pi, pi, (1.0, 1.0, 0.0, 0.0), z3, z3, cams, step=0)        # gradients only needs g_cams
+    ctx.close()
+
+
 def test_sharded_ba_step_on_the_gpu_equals_the_fused_form():
     """ShardedMapper.step_ba (nice-slam-cpp_amd/dist.py: what a rank of BASELINE configs[4] runs -- the step with ray gradients, nsk_pose_step_multi with
     step 0 into the buffer registered with nsk_grad_extra, the packed exchange, nsk_adam_step, ONE nsk_adam_vector over every pose of the window) on

@@ -149,7 +149,7 @@ def _mapping_steps_vs_oracle(ctx, o, sc, rays, stage, steps, w_color=0.5, masks=
         far = np.abs(got - ref_k) > 0.1 * 0.005
         assert far.mean() < 1e-2, (k, far.mean())
         e = rel_l2(got[~far], ref_k[~far])
-        assert e < 30 * TOL, (k, e)
+        assert e < 10 * TOL, (k, e)                       # (round 4, rounding of the sampling geometry pinned: measured 5e-7 .. 5.4e-4 over K2 / K3 / K4; was 30)
         report.append("%s free run: %d of %d elements took the other sign, the rest within %.1e%s" % (
             k, far.sum(), far.size, e, "" if len(free) < 2 else " (fp32 and fp64 oracles: %d apart)" % (np.abs(ref_k - free[1]["grids"][k]) > 0.1 * 0.005).sum()))
     if stage == "color":
@@ -442,15 +442,17 @@ def test_k5_tracker_then_mapper_with_bundle_adjustment(oracle32, oracle64):
     # Measured on this batch (tools/dbg_k5.py): ONE of the 200 tracking rays has a ReLU input of 5.6e-6 that the bf16-split forward and the
     # fp32 oracle put on different sides of the kink; that ray's gradient changes by 25 %, the pose gradient by 5.6e-3, and Adam's
     # normalised steps turn that into 2e-4 of the pose after three iterations (with the fp32-MFMA forward, nsk_set_matmul_mode(ctx, 0),
-    # the same batch agrees to 2e-4 in the gradient).  Hence: within 1e-4, or within the fp64 arbiter's bound, or within 3e-3 (the BA pose takes three more Adam steps from the tracked one).
+    # the same batch agrees to 2e-4 in the gradient).  That was round 3 (sample points an ulp from the oracle's wherever hipcc had fused o + d z);
+    # since round 4 the HIP path and the fp32 oracle see the same sample points and embedding arguments bit for bit: tracked pose 4.8e-7, BA pose
+    # 5.4e-5.  Hence: within 1e-4 of the fp32 oracle, no other arm.
     for name, got, r32, r64 in (("tracked pose", trk_g, trk_32, trk_64), ("BA pose", cam_g, cam_32, cam_64)):
         e, e64, eo = rel_l2(got, r32), rel_l2(got, r64), rel_l2(r32, r64)
-        assert e < TOL or e64 < max(TOL, 2 * eo) or e < 30 * TOL, "%s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (name, e, e64, eo)
+        assert e < TOL, "%s: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (name, e, e64, eo)
     for k in LEVELS["color"]:          # free run: elements whose gradient sign is decided by rounding are counted, the rest must agree
         far = np.abs(grids_g[k] - grids_32[k]) > 0.1 * 0.005                       # (see _mapping_steps_vs_oracle; here the two runs also
         assert far.mean() < 0.15, (k, far.mean())                                 # map from poses 2e-4 apart, so more signs are open)
         e = rel_l2(grids_g[k][~far], grids_32[k][~far])
-        assert e < 30 * TOL, (k, e)
+        assert e < 10 * TOL, (k, e)
     e, e64, eo = rel_l2(dec_g, dec_32), rel_l2(dec_g, dec_64), rel_l2(dec_32, dec_64)
     assert e < TOL or e64 < 2 * eo + TOL, "colour decoder: hip-vs-f32 %.2e hip-vs-f64 %.2e f32-vs-f64 %.2e" % (e, e64, eo)
     assert e < 50 * TOL

@@ -297,8 +297,10 @@ def test_mapper_run_matches_oracle_on_the_same_pixel_draws(dump, oracle32, oracl
     assert np.array_equal(est1[:5], dump["mo_poses_0"][:5])                                  # frames before BA keep their given poses
     # Bundle adjustment: the pose gradient sums, over 40 rays x 48 samples per frame, terms of size |B| ~ 25..75 times the decoder gradient with
     # both signs -- with these random decoders a handful of ReLU flips moves it by tens of percent (the fp32 and fp64 ORACLES differ by 3 % on
-    # it), so it is compared in direction only (the ray-gradient kernels are held to 1e-4 on non-fragile rays in tests/test_gpu_parity.py),
-    # and the step is teacher-forced: the oracle's Adam and quad2rotation applied to the GPU's own gradient must give the GPU's poses.
+    # it).  Until round 3 the GPU's gradient therefore agreed with the fp32 oracle's "in direction only" (cos 0.86 .. 0.99); since round 4 both see
+    # the same sample points and embedding arguments bit for bit and take (all but a handful of) the same branches: the gradients must agree to
+    # 1e-2 relative and cos > 0.9999 (measured: 2.7e-3 at worst, cos 1.000 on all four frames) -- and the step is still teacher-forced: the oracle's Adam and quad2rotation applied to the GPU's own gradient
+    # must give the GPU's poses.
     bg = dump["mo_ba_grad"]
     assert bg.shape == bg32.shape and [int(f) for f in got_w[5]] == list(win)
     cosines, nba = [], 0
@@ -316,7 +318,10 @@ def test_mapper_run_matches_oracle_on_the_same_pixel_draws(dump, oracle32, oracl
         o.adam_step(cam, bg[i].astype(np.float32), m, v, 1e-3, 1)
         ref = o.camera_from_tensor(cam)
         assert np.abs(pose_gpu[:3] - ref).max() < 2e-6, (i, f, pose_gpu[:3], ref)
-    assert nba == 4 and min(cosines) > 0.5, cosines
+    assert nba == 4 and min(cosines) > 0.9999, cosines
+    for i in range(len(win)):
+        if np.any(bg32[i]):
+            assert rel_l2(bg[i], bg32[i]) < 1e-2, (i, rel_l2(bg[i], bg32[i]))
     e_pose, eo_pose = rel_l2(est1[5][:3], est32[5][:3]), rel_l2(est32[5][:3], est64[5][:3])
     flips = {}
     for k in ("middle", "fine", "color"):

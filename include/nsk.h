@@ -98,7 +98,9 @@ int nsk_set_sort_mode(nsk_ctx* ctx, int mode);
  *   "roctx" 1:         roctxRangePush/Pop around every launch group (names as in nsk_profile_end) for rocprofv3 --marker-trace;
  *   "frozen_cost" n:   relative cost of a frozen decoder's tile in the backward's workgroup split (0 = built-in value);
  *   "no_fused_median" 1: nsk_track_step computes the Tracker's median threshold in a launch of its own (composite, median, composite)
- *                      even where the one-launch form applies;
+ *                      even where a fused form applies;
+ *   "no_deferred_median" 1: with ray gradients and frozen decoders the threshold is found inside the compositing launch behind a grid
+ *                      barrier (round 3's form) instead of by the backward launch's workgroups;
  *   "no_piggyback" 1:  a batch registered with nsk_map_prepare is sampled by launches of its own at the start of its step. */
 int nsk_set_tuning(nsk_ctx* ctx, const char* key, int value);
 

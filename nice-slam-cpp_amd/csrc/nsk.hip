@@ -800,6 +800,7 @@ struct nsk_ctx {
     int tune_fwd_fine_cost = 0, tune_fwd_color_cost = 0;     // experiments: forward role costs (nsk_set_tuning "fwd_fine_cost" / "fwd_color_cost")
     int tune_skew = 0;                      // start offset of the upper four waves of a decoder workgroup, x 1024 cycles (wave_skew, nsk_device.h)
     bool median_fused_pending = false;
+    int tune_no_deferred_median = 0;        // 1: the threshold inside the compositing launch (grid barrier) even where the backward could find it (round 3's form)
     int tune_no_fused_median = 0;           // 1: the Tracker's median threshold in its own launch even where the fused form applies (experiments, tests)
     int tune_frozen_cost = 0;               // > 0: overrides the frozen-role cost of the backward's workgroup split (nsk_set_tuning; experiments)
     int tune_frozen_cost_rays = 0;          // > 0: the same for launches with ray gradients (bundle adjustment: the frozen roles also carry g_e and d/dp)
@@ -934,7 +935,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8, 2>, 160 * 1024));
     CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024 - 256)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));      // (<false>, frozen: the scan role keeps a few words of static LDS)
     CHK(set_lds(k_decode_bwd_frozen<false>, 160 * 1024 - 256));
-    CHK(set_lds(k_decode_bwd_multi_full<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi_full<true>, 160 * 1024));
+    CHK(set_lds(k_decode_bwd_track, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi_full<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi_full<true>, 160 * 1024));
     CHK(set_lds(k_decode_fwd_dump<0>, 160 * 1024)); CHK(set_lds(k_decode_fwd_dump<1>, 160 * 1024)); CHK(set_lds(k_decode_fwd_dump<2>, 160 * 1024));
     *out = c;
     return 0;
@@ -1019,6 +1020,7 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
     if (!strcmp(key, "no_piggyback")) { c->tune_no_piggyback = value; return 0; }
     if (!strcmp(key, "frozen_mid_pct")) { if (value < 10 || value > 1000) return fail("nsk_set_tuning: frozen_mid_pct out of range"); c->tune_frozen_mid_pct = value; return 0; }
     if (!strcmp(key, "no_fused_median")) { c->tune_no_fused_median = value; return 0; }
+    if (!strcmp(key, "no_deferred_median")) { c->tune_no_deferred_median = value; return 0; }
     if (!strcmp(key, "fwd_fine_cost")) { c->tune_fwd_fine_cost = value; return 0; }
     if (!strcmp(key, "fwd_color_cost")) { c->tune_fwd_color_cost = value; return 0; }
     if (!strcmp(key, "skew")) { if (value < 0 || value > 299) return fail("nsk_set_tuning: skew out of range"); c->tune_skew = value; return 0; }
@@ -1920,8 +1922,9 @@ static int flush_pending(nsk_ctx* c)
     return 0;
 }
 
+// dyn_resid: the Tracker's deferred median mask (composite mode 5 wrote the residuals there and the seeds to ws.tmp_rgb): k_decode_bwd_track
 static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, const float* rd, unsigned flags, float* g_ro, float* g_rd,
-                         float* d_loss = nullptr)
+                         float* d_loss = nullptr, const float* dyn_resid = nullptr)
 {
     const bool rays = (flags & NSK_GRAD_RAYS) != 0;
     const bool grids = (flags & NSK_GRAD_GRIDS) != 0;
@@ -1941,6 +1944,7 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         A.masks = c->ws.masks[w];
         A.g_raw = c->ws.g_raw;
         A.g_rays_o = g_ro; A.g_rays_d = g_rd;
+        A.dyn_resid = dyn_resid; A.dyn_n = N;
         A.g_dec = train ? c->ws.dec_slabs : c->slab + c->dec[w].g_off;
 #ifdef NSK_EXPERIMENT
         A.flags = flags & 0xffffu;                                  // experiment builds pass the debug bits 9.. through (tools/exp_bwd.py)
@@ -1963,6 +1967,8 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
         if (grids) c->touched[NSK_GROUP_COARSE + w] = true;
         ++n;
     }
+    if (dyn_resid && (train_role != -1 || !rays || c->deterministic || c->bwd_mode == 0 || n == 0 || N > NSK_MEDIAN_FUSED_MAX))
+        return fail("backward_core: the deferred median mask needs the Tracker's launch (frozen decoders, ray gradients)");      // the caller checked the same
     const int separate = c->deterministic ? 1 : 0;      // debug mode: one launch per decoder, in a fixed order
     if ((n == 0 || train_role == -2 || separate) && d_loss) { ProfScope ps(c, "loss_sum"); k_sum<<<1, 1024, 0, c->stream>>>(N, c->ws.ray_loss, d_loss); }
     if (n == 0) return 0;
@@ -1992,7 +1998,10 @@ static int backward_core(nsk_ctx* c, int stage, int N, int S, const float* ro, c
     }
     {
         ProfScope ps(c, "decode_bwd_multi");
-        if (full) {
+        if (dyn_resid) {
+            MA.dyn_seed = c->ws.tmp_rgb; MA.dyn_thr_out = c->scal + 1;
+            k_decode_bwd_track<<<MA.wg_end[n - 1] + 1, 512, lds + NSK_DYN_LDS_BYTES, c->stream>>>(MA);
+        } else if (full) {
             size_t ldsf = 0;
             for (int r = 0; r < n; ++r) {
                 const int w = MA.which[r];
@@ -2149,19 +2158,28 @@ extern "C" int nsk_track_step(nsk_ctx* c, int stage, int N, const float* ro, con
     // (round 3 tried ONE 16-wave workgroup for up to 256 rays -- render, select the median in LDS, render again, no grid barrier: 70 us at 200 rays
     // against 21, a wave's rays run one after the other at ~2.5 us each)
     const bool fused_median = handle_dynamic && !c->deterministic && !c->tune_no_fused_median && N <= NSK_MEDIAN_FUSED_MAX && (N + 3) / 4 <= c->num_cu;
-    if (handle_dynamic && !fused_median) {                     // forward pass for the median (Tracker.cpp:69-70)
+    // Round 4: with ray gradients and frozen decoders (the Tracker as the reference runs it) not even that barrier -- the mask is one factor per
+    // ray on what the compositing hands on, and the backward's workgroups apply it (composite mode 5, k_decode_bwd_track)
+    bool deferred = handle_dynamic && !c->deterministic && !c->tune_no_fused_median && !c->tune_no_deferred_median && N <= NSK_MEDIAN_FUSED_MAX &&
+                    (flags & NSK_GRAD_RAYS) && c->bwd_mode != 0;
+    for (int q = 0; q < 3 && deferred; ++q) {
+        const int w = STAGE_DEC[stage][q];
+        if (w >= 0 && (flags & NSK_GRAD_DECODERS) && c->dec[w].trainable) deferred = false;
+    }
+    if (handle_dynamic && !fused_median && !deferred) {                     // forward pass for the median (Tracker.cpp:69-70)
         A.mode = 0; A.depth = c->ws.tmp_depth;
         k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A);
         CHK(median_thr(c, N, gt, c->ws.tmp_depth));
         A.depth = nullptr;
     }
-    A.mode = fused_median ? 4 : 3; A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
+    A.mode = deferred ? 5 : (fused_median ? 4 : 3); A.gt_depth = gt; A.gt_color = gtc; A.w_color = w_color; A.use_color = use_color;
     A.thr = c->scal + 1; A.handle_dynamic = handle_dynamic; A.detach_var = detach_var; A.loss = c->ws.ray_loss;
-    if (fused_median) { c->median_fused_pending = true; A.resid = c->ws.tmp_depth; A.bar = reinterpret_cast<unsigned*>(c->scal + 5); A.thr_out = c->scal + 1; }
+    if (deferred) { A.resid = c->ws.tmp_depth; A.g_seed = c->ws.tmp_rgb; }
+    else if (fused_median) { c->median_fused_pending = true; A.resid = c->ws.tmp_depth; A.bar = reinterpret_cast<unsigned*>(c->scal + 5); A.thr_out = c->scal + 1; }
     if (flags & NSK_GRAD_RAYS) { A.g_rays_o = g_ro; A.g_rays_d = g_rd; }
     { ProfScope ps(c, "composite"); k_composite<<<(N + 3) / 4, 256, 0, c->stream>>>(A); }
     HIPCHK(hipGetLastError());
-    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd, d_loss));
+    CHK(backward_core(c, stage, N, S, ro, rd, flags, g_ro, g_rd, d_loss, deferred ? c->ws.tmp_depth : nullptr));
     account(c, stage, N * S, N, true, flags);
     return 0;
 }

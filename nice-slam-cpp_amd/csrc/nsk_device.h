@@ -844,6 +844,8 @@ struct DecArgs {
     unsigned flags;
     float* dump;              // test aid (nsk_debug_preact): ReLU inputs [M][5][32] by sample, or nullptr
     int skew;                 // start offset of a workgroup's upper four waves, in units of 1024 cycles (wave_skew)
+    const float* dyn_resid;   // k_decode_bwd_track: per-ray |gt - depth| [dyn_n] (+inf: ray masked) -- the Tracker's median mask is applied HERE (see lower_median_x10)
+    int dyn_n;
 };
 
 // The two waves that share a SIMD (w and w + 4 of a 512-thread workgroup) start a kernel in step, and a tile is a long vector-unit
@@ -1008,6 +1010,7 @@ struct MultiArgs {
     DecArgs a[3]; int which[3]; int train[3]; int wg_end[3]; int n;
     const float* sum_src; float* sum_dst; int sum_n;      // optional: one extra workgroup sums the per-ray losses (saves a launch)
     ScanArgs scan;                                        // optional (scan.nblocks > 0): the NEXT batch's cell-sort offsets ride behind the roles (nsk_map_prepare)
+    const float* dyn_seed; float* dyn_thr_out;            // k_decode_bwd_track's last workgroup: the compositing's own d/d rays_d term [N][3], 10 x median (scalar)
 };
 
 __device__ __forceinline__ void block_sum(const float* __restrict__ x, int n, float* __restrict__ out)
@@ -1070,6 +1073,7 @@ struct CompArgs {
     float* loss;                                                              // modes 2,3: per-ray loss [N] or nullptr
     float* g_raw;                                                             // [M][4]
     float* g_rays_o; float* g_rays_d;                                         // [N][3] seeds or nullptr
+    float* g_seed;                                                            // mode 5: [N][3] the d/d rays_d term of the compositing itself (g_rays_d gets 0)
     const uint8_t* keep;                                                      // [N] or nullptr: rays with keep == 0 are rendered but take no part in
                                                                               // the loss or its gradient (nsk_set_ray_mask: the reference drops them)
 };
@@ -1109,6 +1113,65 @@ __device__ __forceinline__ float median_select(const float* __restrict__ rs, int
         if (tot <= target) ans = cand;
     }
     return __uint_as_float(ans);
+}
+
+// Mode 5 (round 4): the Tracker's loss with the median mask DEFERRED to the backward launch.  The mask `|gt - depth| < 10 median` (Tracker.cpp:69-71)
+// is one factor per ray on everything this kernel hands on -- g_raw, the per-ray loss, the compositing's own d/d rays_d term -- so this kernel writes
+// them as if every ray passed, plus the residuals, and needs no grid barrier (mode 4's cost 12 of its 21 us at 200 rays); every workgroup of
+// k_decode_bwd_track then finds the threshold from the residuals while its weight image and first tile are in flight, and zeroes g_raw of the
+// rays that fail.  No inter-workgroup protocol is left: the residuals are ordinary stores of the previous launch.
+// 10 x the lower median (torch.median) of the residuals in rs[0..n4) (non-negative or NaN; +inf = masked ray, padding); every thread of the
+// NT-thread workgroup calls it after a barrier that made rs visible, and every thread gets the value.  part: 3 * NT / 64 ints of LDS.
+template <int NT, int MAXN>
+__device__ __forceinline__ float lower_median_x10(const float* __restrict__ rs, int n4, int* __restrict__ part)
+{
+    constexpr int NWV = NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Counting is by ballot (a compare into a scalar pair + s_bcnt1): a first version summed per-lane counts with wave_sum and met at a barrier
+    // in each of the 32 passes -- 12 us on every workgroup of the Tracker's backward (tools/track_times.py: 15.4 -> 27.2 us).
+    if (n4 <= 256) {
+        // up to 256 rays (the Tracker's 200): every WAVE selects on its own -- four residuals per lane, 4 compares + 4 s_bcnt1 per pass, no LDS
+        // traffic and no barrier inside the 32 passes
+        unsigned u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; u[e] = i < n4 ? __float_as_uint(rs[i]) : 0xffffffffu; }
+        auto below = [&](unsigned cand) {
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c += __popcll(__builtin_amdgcn_ballot_w64(u[e] < cand));
+            return c;
+        };
+        const int target = (max(below(0x7f800000u), 1) - 1) / 2;      // finite residuals: masked rays and NaN renderings sort behind them
+        unsigned ans = 0u;
+        for (int bit = 30; bit >= 0; --bit) {
+            const unsigned cand = ans | (1u << bit);
+            if (below(cand) <= target) ans = cand;
+        }
+        return 10.f * __uint_as_float(ans);
+    }
+    constexpr int PER = (MAXN + NT - 1) / NT;
+    unsigned u[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { const int i = threadIdx.x + e * NT; u[e] = i < n4 ? __float_as_uint(rs[i]) : 0xffffffffu; }
+    auto below = [&](unsigned cand, int buf) {                 // how many residuals have a bit pattern below cand (all threads get the total)
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) cnt += __popcll(__builtin_amdgcn_ballot_w64(u[e] < cand));
+        if (lane == 0) part[buf * NWV + wave] = cnt;
+        __syncthreads();
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) tot += part[buf * NWV + w];
+        return tot;
+    };
+    const int valid = below(0x7f800000u, 2);
+    const int target = (max(valid, 1) - 1) / 2;
+    unsigned ans = 0u;
+    for (int bit = 30; bit >= 0; --bit) {
+        const unsigned cand = ans | (1u << bit);
+        if (below(cand, bit & 1) <= target) ans = cand;
+    }
+    return 10.f * __uint_as_float(ans);
 }
 
 template <int RPW>           // rays (waves) per workgroup; bid / nb: this role's workgroup index and count inside the launch
@@ -1166,6 +1229,7 @@ __device__ __forceinline__ void composite_body(const CompArgs& A, int bid, int n
     if (A.mode == 0) return;
     const bool kept = !A.keep || A.keep[n];
     float thr_here = 0.f;
+    if (A.mode == 5 && lane == 0) A.resid[n] = kept ? fabsf(A.gt_depth[n] - D) : NSK_INF;
     if (A.mode == 4) {
         __shared__ __attribute__((aligned(16))) float rs[NSK_MEDIAN_FUSED_MAX];
         __shared__ float s_thr;
@@ -1218,7 +1282,7 @@ __device__ __forceinline__ void composite_body(const CompArgs& A, int bid, int n
         // inf / NaN, and 0 * NaN would otherwise reach the grids: tests/test_gpu_configs.py::test_fully_masked_batch_is_a_no_op)
         if (A.loss && lane == 0) A.loss[n] = 0.f;
         if (act) *reinterpret_cast<f4*>(A.g_raw + m * 4) = (f4)(0.f);
-        if (A.g_rays_d && lane < 3) { A.g_rays_d[3 * n + lane] = 0.f; A.g_rays_o[3 * n + lane] = 0.f; }
+        if (A.g_rays_d && lane < 3) { A.g_rays_d[3 * n + lane] = 0.f; A.g_rays_o[3 * n + lane] = 0.f; if (A.mode == 5) A.g_seed[3 * n + lane] = 0.f; }
         return;
     } else if (A.mode == 1) {
         gD = A.g_depth ? A.g_depth[n] : 0.f;
@@ -1237,7 +1301,7 @@ __device__ __forceinline__ void composite_body(const CompArgs& A, int bid, int n
                 for (int k = 0; k < 3; ++k) gC[k] = -A.w_color * sgnf(rc[k]);
             }
         } else {                                                // Tracker.cpp:67-82
-            bool mk = gtd > 0.f && (!A.handle_dynamic || fabsf(r) < (A.mode == 4 ? thr_here : *A.thr));
+            bool mk = gtd > 0.f && (!A.handle_dynamic || A.mode == 5 || fabsf(r) < (A.mode == 4 ? thr_here : *A.thr));
             if (mk) {
                 float u = sqrtf(V + 1e-10f);
                 lsum += fabsf(r) / u;
@@ -1277,7 +1341,9 @@ __device__ __forceinline__ void composite_body(const CompArgs& A, int bid, int n
         float gn = wave_sum(act ? g_n : 0.f);
         if (lane < 3) {
             float dk = lane == 0 ? dx : (lane == 1 ? dy : dz);
-            A.g_rays_d[3 * n + lane] = nrm > 0.f ? gn * dk / nrm : 0.f;      // utils.h:153 norm(rays_d)
+            const float seed = nrm > 0.f ? gn * dk / nrm : 0.f;              // utils.h:153 norm(rays_d)
+            if (A.mode == 5) { A.g_seed[3 * n + lane] = seed; A.g_rays_d[3 * n + lane] = 0.f; }      // added by k_decode_bwd_track's last workgroup if the ray passes
+            else A.g_rays_d[3 * n + lane] = seed;
             A.g_rays_o[3 * n + lane] = 0.f;
         }
     }
@@ -1425,9 +1491,10 @@ __device__ __forceinline__ void image_commit(f4* __restrict__ dst, const ImgRegs
 }
 
 // ------------------------------------------------------------------------------------------------------
-template <int WHICH, bool RAYS, int NW = 8, bool FULL = false>      // FULL: the chain on the fp32 MFMA whatever RAYS says (nsk_set_backward_mode 0)
-__device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int nb)
+template <int WHICH, bool RAYS, int NW = 8, bool FULL = false, bool DYN = false>      // FULL: the chain on the fp32 MFMA whatever RAYS says (nsk_set_backward_mode 0)
+__device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int nb)          // DYN: the Tracker's median mask is found and applied here (composite mode 5)
 {
+    static_assert(!DYN || RAYS, "the deferred median mask belongs to the Tracker's ray-gradient launch");
     constexpr bool XYZ = WHICH != 0;
     constexpr int OD = WHICH == 3 ? 4 : 1;
     constexpr bool NEED_E = XYZ && RAYS;
@@ -1440,6 +1507,8 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     float* smf = reinterpret_cast<float*>(smem);
     float* scratch = smf + IMG_F + wave * 960;                  // per-wave scatter scratch (3840 B)
+    float* dyn_rs = smf + IMG_F + NW * 960;                     // DYN: the residuals [NSK_MEDIAN_FUSED_MAX], then 3 * NW counters (NSK_DYN_LDS_BYTES)
+    float dyn_thr = 0.f;
     const f4* img_src = B16 ? reinterpret_cast<const f4*>(A.bimg16) : A.bimg;
     constexpr int IMG_K = (IMG_F / 4 + 64 * NW - 1) / (64 * NW) < 8 ? (IMG_F / 4 + 64 * NW - 1) / (64 * NW) : 8;
     ImgRegs<IMG_K> img_regs;
@@ -1472,8 +1541,20 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         const int mm0 = slot_sample(A, slot_of(tile_of(0, wg, nw, tsh)));
         image_issue<64 * NW>(img_regs, img_src, IMG_F / 4);
         stage(tile_of(0, wg, nw, tsh), mm0, nx);
-        image_commit<64 * NW>(smem, img_regs, img_src, IMG_F / 4);
-        __syncthreads();
+        if constexpr (DYN) {
+            constexpr int PER = (NSK_MEDIAN_FUSED_MAX + 64 * NW - 1) / (64 * NW);
+            float rv[PER];
+#pragma unroll
+            for (int e = 0; e < PER; ++e) { const int i = (int)threadIdx.x + e * 64 * NW; rv[e] = i < A.dyn_n ? A.dyn_resid[i] : NSK_INF; }
+            image_commit<64 * NW>(smem, img_regs, img_src, IMG_F / 4);
+#pragma unroll
+            for (int e = 0; e < PER; ++e) { const int i = (int)threadIdx.x + e * 64 * NW; if (i < NSK_MEDIAN_FUSED_MAX) dyn_rs[i] = rv[e]; }
+            __syncthreads();
+            dyn_thr = lower_median_x10<64 * NW, NSK_MEDIAN_FUSED_MAX>(dyn_rs, (A.dyn_n + 3) & ~3, reinterpret_cast<int*>(dyn_rs + NSK_MEDIAN_FUSED_MAX));
+        } else {
+            image_commit<64 * NW>(smem, img_regs, img_src, IMG_F / 4);
+            __syncthreads();
+        }
     }
     int mm_next = slot_sample(A, slot_of(tile_of(1, wg, nw, tsh)));
     const bool det = (A.flags & 0x8000u) != 0;      // deterministic debug mode: every wave walks all kmax rounds (they meet at barriers)
@@ -1494,6 +1575,7 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         {
             f4 gr = nx.gr;
             if (!valid) gr = (f4)(0.f);
+            if constexpr (DYN) { if (!(dyn_rs[n] < dyn_thr)) gr = (f4)(0.f); }        // the ray fails |gt - depth| < 10 median: Tracker.cpp:71
             if constexpr (OD == 4) { gout[0] = gr[0]; gout[1] = gr[1]; gout[2] = gr[2]; gout[3] = 0.f; }
             else gout[0] = gr[3];
         }
@@ -1643,5 +1725,50 @@ __global__ __launch_bounds__(64 * NSK_FROZEN_NW) void k_decode_bwd_frozen(MultiA
     case 1: decode_bwd_body<1, RAYS, NSK_FROZEN_NW>(MA.a[r], bid, nb); break;
     case 2: decode_bwd_body<2, RAYS, NSK_FROZEN_NW>(MA.a[r], bid, nb); break;
     default: decode_bwd_body<3, RAYS, NSK_FROZEN_NW>(MA.a[r], bid, nb); break;
+    }
+}
+
+// The Tracker's backward (frozen decoders, ray gradients, handle_dynamic): every role's workgroups find the median threshold themselves (composite
+// mode 5 left the residuals) and drop the rays that fail it; the launch's last workgroup does the same for what the compositing handed over per
+// ray: the loss terms (summed in block_sum's order, so the loss has the bits of the three-launch form) and the d/d rays_d term of the
+// compositing itself, which it adds to g_rays_d (zeroed by the compositing) beside the roles' own atomic adds.
+#define NSK_DYN_LDS_BYTES (NSK_MEDIAN_FUSED_MAX * 4 + 3 * 8 * 4)
+__global__ __launch_bounds__(512) void k_decode_bwd_track(MultiArgs MA)
+{
+    if (blockIdx.x == gridDim.x - 1) {
+        extern __shared__ __attribute__((aligned(16))) f4 smem[];
+        float* rs = reinterpret_cast<float*>(smem);
+        const DecArgs& A = MA.a[0];
+        for (int i = threadIdx.x; i < NSK_MEDIAN_FUSED_MAX; i += 512) rs[i] = i < A.dyn_n ? A.dyn_resid[i] : NSK_INF;
+        __syncthreads();
+        const float thr = lower_median_x10<512, NSK_MEDIAN_FUSED_MAX>(rs, (A.dyn_n + 3) & ~3, reinterpret_cast<int*>(rs + NSK_MEDIAN_FUSED_MAX));
+        if (threadIdx.x == 0 && MA.dyn_thr_out) *MA.dyn_thr_out = thr;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < A.dyn_n; i += 512) {
+            const bool pass = rs[i] < thr;
+            if (MA.sum_n > 0) s += pass ? MA.sum_src[i] : 0.f;
+            if (pass && A.g_rays_d) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(A.g_rays_d + 3 * i + k, MA.dyn_seed[3 * i + k]);
+            }
+        }
+        if (MA.sum_n > 0) {
+            __syncthreads();                                   // rs is reused for the partial sums
+            s = wave_sum(s);
+            if ((threadIdx.x & 63) == 0) rs[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) { for (int w = 1; w < 8; ++w) s += rs[w]; *MA.sum_dst = s; }
+        }
+        return;
+    }
+    int r = 0;
+    while (r < MA.n - 1 && (int)blockIdx.x >= MA.wg_end[r]) ++r;
+    const int b0 = r == 0 ? 0 : MA.wg_end[r - 1];
+    const int bid = blockIdx.x - b0, nb = MA.wg_end[r] - b0;
+    switch (MA.which[r]) {
+    case 0: decode_bwd_body<0, true, 8, false, true>(MA.a[r], bid, nb); break;
+    case 1: decode_bwd_body<1, true, 8, false, true>(MA.a[r], bid, nb); break;
+    case 2: decode_bwd_body<2, true, 8, false, true>(MA.a[r], bid, nb); break;
+    default: decode_bwd_body<3, true, 8, false, true>(MA.a[r], bid, nb); break;
     }
 }

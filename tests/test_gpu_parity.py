@@ -422,15 +422,19 @@ def test_tracking_steps_match_oracle(oracle32, oracle64):
 
 @pytest.mark.parametrize("n_rays,masked", [(200, False), (37, True), (1023, False), (1500, False), (1, False), (2, True), (5, False), (1000, True)])
 def test_tracker_median_in_the_composite_launch(n_rays, masked):
-    """Tracker.cpp:67-71: the 10 x median threshold computed inside the loss launch (k_composite mode 4: residuals, grid barrier, selection
-    by bisection on the bit pattern) gives the bits of the three-launch form (composite, k_median_thr, composite); ray counts that are not a multiple of the
-    four rays of a workgroup, a ray mask, and a batch above the fused form's limit (1500 rays: both runs take the three launches)"""
+    """Tracker.cpp:67-71: the 10 x median threshold in its three forms -- found by every workgroup of the BACKWARD launch from residuals the
+    compositing left (composite mode 5 + k_decode_bwd_track: the default with ray gradients, no barrier anywhere), found inside the loss launch
+    behind a grid barrier (k_composite mode 4: round 3's form, still what a call without ray gradients takes), and the three-launch form
+    (composite, k_median_thr, composite) -- gives the same loss bits and the same ray gradients; ray counts that are not a multiple of the four
+    rays of a workgroup, a ray mask, and a batch above the fused forms' limit (1500 rays: all runs take the three launches)"""
     sc = _scene(33, grid_std=0.3)
     rays = scenes.make_rays(34, n_rays, sc["bound"], n_frames=1, zero_frac=0.1)
     out = {}
-    for fused in (1, 0):
+    forms = {"deferred": {}, "barrier": {"no_deferred_median": 1}, "three": {"no_fused_median": 1}}
+    for form, tune in forms.items():
         ctx = make_ctx(sc)
-        ctx.set_tuning("no_fused_median", 0 if fused else 1)
+        for k, v in tune.items():
+            ctx.set_tuning(k, v)
         if masked:
             keep = (np.arange(n_rays) % 3 != 0).astype(np.uint8)
             ctx.set_ray_mask(cu(keep, torch.uint8))
@@ -439,10 +443,13 @@ def test_tracker_median_in_the_composite_launch(n_rays, masked):
         for _ in range(3):          # the barrier re-arms itself: three launches in a row
             ctx.track_step("color", ro, rd, gd, gc, -1.0, 0.5, True, True, True, flags=4, loss=loss, g_rays=(g_ro, g_rd))
         ctx.sync()
-        out[fused] = (float(loss), g_ro.cpu().numpy().copy(), g_rd.cpu().numpy().copy())
-    assert out[1][0] == out[0][0], (out[1][0], out[0][0])
-    # the ray gradients are sums of atomics over the samples' tiles: equal up to the order of those adds
-    assert rel_l2(out[1][1], out[0][1]) < 1e-6 and rel_l2(out[1][2], out[0][2]) < 1e-6
+        out[form] = (float(loss), g_ro.cpu().numpy().copy(), g_rd.cpu().numpy().copy())
+    for form in ("deferred", "barrier"):
+        assert out[form][0] == out["three"][0], (form, out[form][0], out["three"][0])
+        # the ray gradients are sums of atomics over the samples' tiles: equal up to the order of those adds
+        assert rel_l2(out[form][1], out["three"][1]) < 1e-6 and rel_l2(out[form][2], out["three"][2]) < 1e-6, form
+        # and a ray the threshold drops has an exactly zero gradient in every form
+        assert np.array_equal(np.all(out[form][2] == 0, axis=1), np.all(out["three"][2] == 0, axis=1)), form
 
 
 @pytest.mark.parametrize("stage", ["fine", "color"])

@@ -1363,16 +1363,22 @@ __global__ __launch_bounds__(512) void k_composite_sample(CompArgs A, SampArgs P
 //
 // Samples of a tile that share a cell form a run (consecutive along a ray; whole tiles in cell-sorted order).  The sums
 //     out[run][corner][channel] = sum over the run's samples j of  w[j][corner] * g_c[j][channel]
-// are one small matrix product per pair of runs: A = the trilinear weights, masked by run, as a [2 runs x 8 corners] x [16 samples]
-// operand, B = g_c as [16 samples] x [16 channels] (two halves): eight v_mfma_f32_16x16x4_f32 per pair of runs.  The result tile
-// puts channel = lane & 15 and (run, four corners) = lane >> 4 into each lane, so every atomic wave-instruction adds four 64-byte
-// voxel segments.  Operands are transposed through a per-wave LDS scratch; there is no per-sample control flow, only the
-// uniform loop over run pairs (one or two passes in cell-sorted order), which keeps the code a few hundred instructions
-// (the scalar run-walking form it replaces unrolled to ~35 KB per decoder body, most of an instruction cache).
+// are OUTER PRODUCTS accumulated over the run: one v_mfma_f32_4x4x1_16b_f32 per sample (sixteen 4 x 4 blocks = 8 corners x 32 channels, two
+// passes of the matrix pipe), chained through its accumulator while the run lasts.  Block b = lane >> 2 is (corner half cg = b >> 3, channel
+// quad ch = b & 7); a lane feeds w[4 cg + (lane & 3)] as the A row and g_c[4 ch + (lane & 3)] as the B column and receives, in result
+// register i, the sum for corner 4 cg + i and channel 4 ch + (lane & 3): so each of a run's four atomic wave-instructions adds two whole
+// 128-byte voxel rows.  Operands for all sixteen samples are read from the per-wave LDS scratch up front (eight 16-byte reads); inside the
+// walk over the samples nothing depends on a load except the voxel indices of the next run, fetched one sample ahead.  The branches of the
+// walk (does a run start here?) are uniform: the run starts are one scalar bit mask.
+// Until round 4 a pair of runs was one [2 runs x 8 corners] x [16 samples] x [32 channels] product on the 16x16x4 fp32 MFMA with the
+// weights masked by run: eight 32-cycle instructions per pair of runs of which, at 1.2 samples per cell, 15 of 16 k-slots multiplied zeros --
+// 1 800 matrix-pipe cycles per tile that also block the SIMD's vector issue (4.1), against 128 here -- followed by a dependent chain run
+// start -> voxel indices -> 64-bit addresses -> atomics, seven times per tile (measured: ~600 cycles per pass, 2 us per tile of a frozen role).
 // The optimiser mask is not consulted: Adam skips masked voxels and clears their gradient (k_adam_multi).
-// scratch (floats): gT[32][20] | wT[8][20] | vT[16][8] (int) | rstart[16] (int)  = 944 floats
+// scratch (floats): gT[32][20] | wT[8][20] | vT[16][8] (int)  = 928 floats
 // ------------------------------------------------------------------------------------------------------
 #define NSK_SCRATCH_FLOATS 944
+__device__ __forceinline__ f4 mfma_outer(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const f4 (&gc)[2], int lane, bool valid,
                                              float* __restrict__ scratch)
 {
@@ -1380,7 +1386,6 @@ __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const
     float* gT = scratch;                                    // [32 channels][20]: column = sample
     float* wT = scratch + 640;                              // [8 corners][20]
     int* vT = reinterpret_cast<int*>(scratch + 800);        // [16 samples][8 corners] voxel indices
-    int* rstart = reinterpret_cast<int*>(scratch + 928);    // first sample of each run
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         gT[(4 * g + i) * 20 + j] = valid ? gc[0][i] : 0.f;
@@ -1390,51 +1395,44 @@ __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const
     const int cell = T.vox[0];
     const int prev = __shfl_up(cell, 1);
     const bool st = j == 0 || cell != prev;
-    const unsigned mask16 = (unsigned)(__builtin_amdgcn_ballot_w64(st) & 0xffffull);
-    const int R = __builtin_popcount(mask16);
+    const unsigned mask16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(st) & 0xffffull));
     if (g == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) wT[c * 20 + j] = valid ? T.w[c] : 0.f;
-        if (st) rstart[__builtin_popcount(mask16 & ((2u << j) - 1u)) - 1] = j;
     } else if (g == 1) {
         *reinterpret_cast<int4*>(vT + j * 8) = make_int4(T.vox[0], T.vox[1], T.vox[2], T.vox[3]);
         *reinterpret_cast<int4*>(vT + j * 8 + 4) = make_int4(T.vox[4], T.vox[5], T.vox[6], T.vox[7]);
     }
     lds_fence();
-    // operand view of the lane: row / column r16 = lane & 15, samples 4g .. 4g+3
-    const int r16 = j;
-    const f4 B0 = *reinterpret_cast<const f4*>(gT + r16 * 20 + 4 * g);
-    const f4 B1 = *reinterpret_cast<const f4*>(gT + (16 + r16) * 20 + 4 * g);
-    const f4 Wq = *reinterpret_cast<const f4*>(wT + (r16 & 7) * 20 + 4 * g);
-    int rj[4];
+    const int q = lane & 3, cg = lane >> 5, ch = (lane >> 2) & 7;
+    const float* arow = wT + (4 * cg + q) * 20;             // this lane's A row: the weights of corner 4 cg + q, by sample
+    const float* brow = gT + (4 * ch + q) * 20;             // this lane's B column: channel 4 ch + q, by sample
+    const int* vrow = vT + 4 * cg;                          // + 8 s: the voxel indices of this lane's four corners at sample s
+    char* const gbase = reinterpret_cast<char*>(G.g);
+    const unsigned coff = (unsigned)(4 * ch + q) * 4u;      // byte offset of the lane's channel inside a voxel row (128 bytes; a level has < 2^25 voxels)
+    f4 d = (f4)(0.f);
+    int4 vrun = *reinterpret_cast<const int4*>(vrow), vnext = vrun;
+    auto flush = [&]() {
+        const int v4[4] = {vrun.x, vrun.y, vrun.z, vrun.w};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) rj[t] = __builtin_popcount(mask16 & ((2u << (4 * g + t)) - 1u)) - 1;
-    float* const gcol = G.g + r16;
-    // (Round 4 tried a sample-walking form for tiles of many short runs -- the same lane mapping and atomics, the sums by six LDS reads and
-    // eight FMAs per sample of the run instead of eight fp32 MFMAs per pair of runs: K2 backward 70.1 -> 68.8 us, K4 shard 72.2 -> 73.4, K3 205.2 ->
-    // 207.0 on one box: a pass is not bound by its matrix instructions.)
-    for (int p = 0; 2 * p < R; ++p) {                       // uniform: R is a wave-wide scalar
-        const int want = 2 * p + (r16 >> 3);
-        f4 d0 = (f4)(0.f), d1 = (f4)(0.f);
+        for (int i = 0; i < 4; ++i) atomicAdd(reinterpret_cast<float*>(gbase + ((unsigned)v4[i] * 128u + coff)), d[i]);
+    };
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const f4 a4 = *reinterpret_cast<const f4*>(arow + 4 * h);
+        const f4 b4 = *reinterpret_cast<const f4*>(brow + 4 * h);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float a = rj[t] == want ? Wq[t] : 0.f;
-            d0 = mfma4(a, B0[t], d0);
-            d1 = mfma4(a, B1[t], d1);
-        }
-        const int myrun = 2 * p + (g >> 1);                 // result rows 4g+i: run 2p + (g >> 1), corners 4 (g & 1) + i
-        if (myrun < R) {
-            const int js = rstart[myrun];
-            const int4 vx = *reinterpret_cast<const int4*>(vT + js * 8 + 4 * (g & 1));
-            const int v4[4] = {vx.x, vx.y, vx.z, vx.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float* dst = gcol + (size_t)v4[i] * 32;
-                atomicAdd(dst, d0[i]);
-                atomicAdd(dst + 16, d1[i]);
-            }
+            const int s = 4 * h + t;
+            if (s > 0 && ((mask16 >> s) & 1u)) {            // uniform: a run ends in front of sample s
+                flush();
+                vrun = vnext;
+                d = mfma_outer(a4[t], b4[t], (f4)(0.f));
+            } else d = mfma_outer(a4[t], b4[t], d);
+            if (s < 15) vnext = *reinterpret_cast<const int4*>(vrow + 8 * (s + 1));
         }
     }
+    flush();
     lds_fence();
 }
 

@@ -1368,14 +1368,14 @@ __global__ __launch_bounds__(512) void k_composite_sample(CompArgs A, SampArgs P
 // quad ch = b & 7); a lane feeds w[4 cg + (lane & 3)] as the A row and g_c[4 ch + (lane & 3)] as the B column and receives, in result
 // register i, the sum for corner 4 cg + i and channel 4 ch + (lane & 3): so each of a run's four atomic wave-instructions adds two whole
 // 128-byte voxel rows.  Operands for all sixteen samples are read from the per-wave LDS scratch up front (eight 16-byte reads); inside the
-// walk over the samples nothing depends on a load except the voxel indices of the next run, fetched one sample ahead.  The branches of the
-// walk (does a run start here?) are uniform: the run starts are one scalar bit mask.
+// walk over the samples nothing depends on a load: a run's voxel rows come from four v_readlane of its first sample's lane.  The branches of
+// the walk (does a run start here?) are uniform: the run starts are one scalar bit mask.
 // Until round 4 a pair of runs was one [2 runs x 8 corners] x [16 samples] x [32 channels] product on the 16x16x4 fp32 MFMA with the
 // weights masked by run: eight 32-cycle instructions per pair of runs of which, at 1.2 samples per cell, 15 of 16 k-slots multiplied zeros --
 // 1 800 matrix-pipe cycles per tile that also block the SIMD's vector issue (4.1), against 128 here -- followed by a dependent chain run
 // start -> voxel indices -> 64-bit addresses -> atomics, seven times per tile (measured: ~600 cycles per pass, 2 us per tile of a frozen role).
 // The optimiser mask is not consulted: Adam skips masked voxels and clears their gradient (k_adam_multi).
-// scratch (floats): gT[32][20] | wT[8][20] | vT[16][8] (int)  = 928 floats
+// scratch (floats): gT[32][20] | wT[8][20]  = 800 floats
 // ------------------------------------------------------------------------------------------------------
 #define NSK_SCRATCH_FLOATS 944
 __device__ __forceinline__ f4 mfma_outer(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
@@ -1385,38 +1385,62 @@ __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const
     const int j = lane & 15, g = lane >> 4;
     float* gT = scratch;                                    // [32 channels][20]: column = sample
     float* wT = scratch + 640;                              // [8 corners][20]
-    int* vT = reinterpret_cast<int*>(scratch + 800);        // [16 samples][8 corners] voxel indices
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        gT[(4 * g + i) * 20 + j] = valid ? gc[0][i] : 0.f;
-        gT[(16 + 4 * g + i) * 20 + j] = valid ? gc[1][i] : 0.f;
+    for (int i = 0; i < 4; ++i) {                          // (a sample past the end of the batch is a finite copy of the last one: its zero WEIGHTS below drop it)
+        gT[(4 * g + i) * 20 + j] = gc[0][i];
+        gT[(16 + 4 * g + i) * 20 + j] = gc[1][i];
     }
-    // run starts among the tile's 16 samples (lanes 0..15 carry them; every quarter of the wave holds the same Tri)
+    // run starts among the tile's 16 samples (lanes 0..15 carry them; every quarter of the wave holds the same Tri): the cell of the sample
+    // to the left by a row shift inside the 16 lanes (the row's first lane keeps its own and is a start anyway)
     const int cell = T.vox[0];
-    const int prev = __shfl_up(cell, 1);
+    const int prev = __builtin_amdgcn_update_dpp(cell, cell, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
     const bool st = j == 0 || cell != prev;
     const unsigned mask16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(st) & 0xffffull));
     if (g == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) wT[c * 20 + j] = valid ? T.w[c] : 0.f;
-    } else if (g == 1) {
-        *reinterpret_cast<int4*>(vT + j * 8) = make_int4(T.vox[0], T.vox[1], T.vox[2], T.vox[3]);
-        *reinterpret_cast<int4*>(vT + j * 8 + 4) = make_int4(T.vox[4], T.vox[5], T.vox[6], T.vox[7]);
     }
     lds_fence();
+#ifdef NSK_SCATTER_NO_WALK      // timing experiment: the tile's operands go to LDS, nothing else happens
+    return;
+#endif
     const int q = lane & 3, cg = lane >> 5, ch = (lane >> 2) & 7;
     const float* arow = wT + (4 * cg + q) * 20;             // this lane's A row: the weights of corner 4 cg + q, by sample
     const float* brow = gT + (4 * ch + q) * 20;             // this lane's B column: channel 4 ch + q, by sample
-    const int* vrow = vT + 4 * cg;                          // + 8 s: the voxel indices of this lane's four corners at sample s
     char* const gbase = reinterpret_cast<char*>(G.g);
     const unsigned coff = (unsigned)(4 * ch + q) * 4u;      // byte offset of the lane's channel inside a voxel row (128 bytes; a level has < 2^25 voxels)
+    const unsigned zsel = cg ? 0xffffffffu : 0u;
+#if defined(NSK_EXPERIMENT) && !defined(NSK_SCATTER_PLAIN)
+    const int dbg = __builtin_amdgcn_readfirstlane(nsk_dbg_flags);      // tools/exp_ts.py: 1 no atomics (addresses kept), 2 no matrix instructions (their branches cost ~10 us at 1000 rays: -DNSK_SCATTER_PLAIN leaves them out)
+#else
+    constexpr int dbg = 0;
+#endif
     f4 d = (f4)(0.f);
-    int4 vrun = *reinterpret_cast<const int4*>(vrow), vnext = vrun;
-    auto flush = [&]() {
-        const int v4[4] = {vrun.x, vrun.y, vrun.z, vrun.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(reinterpret_cast<float*>(gbase + ((unsigned)v4[i] * 128u + coff)), d[i]);
+    // The voxel rows of a run: corner c = 4 dz + 2 dy + dx sits at vox[0] + dx ox + dy oy + dz oz (tri_setup: the clamped neighbour along an axis
+    // is the voxel itself or one stride further), so four scalars read from the lane of the run's first sample -- vox[0], vox[1], vox[2], vox[4] --
+    // give all eight: result register i of this lane belongs to corner 4 cg + i = vox[i & 3 pattern] + cg oz.  No LDS, no load latency in the walk
+    // (a first version fetched the rows from LDS one sample ahead and waited ~100 cycles for them at every run start).
+    int s0 = 0, s1 = 0, s2 = 0, s4 = 0;
+    auto run_start = [&](int s) {                            // s is a constant after unrolling
+        s0 = __builtin_amdgcn_readlane(T.vox[0], s); s1 = __builtin_amdgcn_readlane(T.vox[1], s);
+        s2 = __builtin_amdgcn_readlane(T.vox[2], s); s4 = __builtin_amdgcn_readlane(T.vox[4], s);
     };
+    auto flush = [&]() {
+        const unsigned vb = ((unsigned)((s4 - s0) << 7) & zsel) | coff;      // + dz oz (upper half of the wave) + the lane's channel
+        const int sv[4] = {s0, s1, s2, s1 + s2 - s0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* dst = reinterpret_cast<float*>(gbase + (((unsigned)sv[i] << 7) + vb));
+#if defined(NSK_SCATTER_WG_SCOPE)      // timing experiments only: the atomics at workgroup scope (wrong sums across XCDs) / no atomics
+            __hip_atomic_fetch_add(dst, d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif defined(NSK_SCATTER_NO_ATOMICS)
+            asm volatile("" :: "v"(dst), "v"(d[i]));
+#else
+            if (dbg & 1) asm volatile("" :: "v"(dst), "v"(d[i])); else atomicAdd(dst, d[i]);
+#endif
+        }
+    };
+    run_start(0);
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const f4 a4 = *reinterpret_cast<const f4*>(arow + 4 * h);
@@ -1424,12 +1448,12 @@ __device__ __forceinline__ void scatter_tile(const GridD& G, const Tri& T, const
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int s = 4 * h + t;
-            if (s > 0 && ((mask16 >> s) & 1u)) {            // uniform: a run ends in front of sample s
+            if (s > 0 && ((mask16 >> s) & 1u)) {            // uniform: a run ends in front of sample s (an `if` without `else`: one branch per sample)
                 flush();
-                vrun = vnext;
-                d = mfma_outer(a4[t], b4[t], (f4)(0.f));
-            } else d = mfma_outer(a4[t], b4[t], d);
-            if (s < 15) vnext = *reinterpret_cast<const int4*>(vrow + 8 * (s + 1));
+                run_start(s);
+                d = (f4)(0.f);
+            }
+            if (dbg & 2) d[0] += a4[t] * b4[t]; else d = mfma_outer(a4[t], b4[t], d);
         }
     }
     flush();

@@ -3,7 +3,7 @@ python tools/exp_ts.py [rays] [sort_mode] [frozen_cost ...]"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["NSK_LIB"] = os.path.join(ROOT, "nice-slam-cpp_amd", "csrc", "libnsk_exp.so")
+os.environ["NSK_LIB"] = os.environ.get("NSK_EXP_LIB", os.path.join(ROOT, "nice-slam-cpp_amd", "csrc", "libnsk_exp.so"))
 import numpy as np, torch
 import nice_slam_cpp_amd as pkg, scenes
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
@@ -40,7 +40,8 @@ def report(tag, flags=3):
 for cost in COSTS:
     ctx.set_tuning("frozen_cost", cost)
     report("sort %d cost %d base" % (SORT, cost))
-    lib.nsk_dbg_set(ctx.h, 1); report("sort %d cost %d no_atomics(walk kept)" % (SORT, cost)); lib.nsk_dbg_set(ctx.h, 0)
+    for bits, name in ((1, "no_atomics(walk kept)"), (2, "no_scatter_mfma"), (4, "no_voxel_prefetch"), (7, "scatter walk only")):
+        lib.nsk_dbg_set(ctx.h, bits); report("sort %d cost %d %s" % (SORT, cost, name)); lib.nsk_dbg_set(ctx.h, 0)
     report("sort %d cost %d no_scatter" % (SORT, cost), 3 | (1 << 9))
     # (never drop the barriers, bit 12: the scatter's run table shares LDS with the panel -- see tools/exp_bwd.py)
     report("sort %d cost %d no_tiles_put" % (SORT, cost), 3 | (1 << 13) | (1 << 14))

@@ -194,9 +194,11 @@ int nsk_map_step(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const fl
 /* One tracking iteration without the Adam step (src/Tracker.cpp:41-89): render, dynamic-outlier mask
  * |gt_d - d| < 10 median (:67-71), loss sum_mask |gt_d - d| / sqrt(var + 1e-10) + w_color sum_mask |gt_c - c|
  * (:75-82), backward onto the rays.  detach_var: treat depth_var as a constant.
- * With handle_dynamic and at most 1024 rays (and at most one 4-ray workgroup per CU) the median is found inside the loss launch:
- * the residuals meet at a device-wide barrier whose wait is bounded; should it ever time out, that step ran with an infinite
- * threshold and the next nsk_sync returns the error. */
+ * With handle_dynamic and at most 1024 rays the median needs no launch of its own.  With NSK_GRAD_RAYS and no trainable decoder (the
+ * Tracker as the reference runs it) the loss launch writes the residuals and every workgroup of the backward launch selects the
+ * median and drops the rays that fail it; otherwise (and while the grid is at most one 4-ray workgroup per CU) the
+ * median is found inside the loss launch: the residuals meet at a device-wide barrier whose wait is bounded; should it ever time
+ * out, that step ran with an infinite threshold and the next nsk_sync returns the error. */
 int nsk_track_step(nsk_ctx* ctx, int stage, int N, const float* d_rays_o, const float* d_rays_d,
                    const float* d_gt_depth, const float* d_gt_color, float gt_depth_max, float w_color, int use_color,
                    int handle_dynamic, int detach_var, unsigned flags, float* d_loss, float* d_g_rays_o,

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "Mapper.h"
+#include "Tracker.h"
 #include "nsk_host.h"
 #include "torchlib/utils.h"
 
@@ -146,6 +147,28 @@ int main(int argc, char** argv)
             torch::Tensor p = torch::matmul(c2w.clone(), roty(a));
             p.index_put_({Slice(None, 3), 3}, c2w.index({Slice(None, 3), 3}) + torch::tensor({0.05f * a, 0.f, -0.1f * a}));
             est.push_back(p);
+        }
+        // The Tracker's side of the loop at N > 1 (slam_loop.cpp): it runs on rank 0 only (its median couples all rays, src/Tracker.cpp:70) and its
+        // pose reaches every rank as a sum with zeros -- Dist::broadcast0, here through the same exchange hook the Mapper's all-reduce takes.
+        {
+            torch::Tensor cam7 = torch::full({8}, 777.f);                     // what a rank holds before the exchange must not matter
+            if (rank == 0) {
+                Tracker tr(ns, cf, c);
+                tr.set_bound(bound); tr.seed(99);
+                tr.run(dec, color_img, depth_img, est[1], 1);
+                cam7.zero_();
+                cam7.index_put_({Slice(None, 7)}, tr.last_camera_tensor);
+            }
+            if (dist.on()) {
+                float* d_pose = nullptr;
+                if (hipMalloc((void**)&d_pose, 8 * sizeof(float)) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+                if (hipMemcpy(d_pose, cam7.data_ptr<float>(), 8 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("H2D failed");
+                dist.broadcast0(d_pose, 8);
+                nskh::check(nsk_sync(nskh::ctx()));
+                if (hipMemcpy(cam7.data_ptr<float>(), d_pose, 8 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("D2H failed");
+                (void)hipFree(d_pose);
+            }
+            save_npy(out + "tracked.npy", cam7);
         }
         torch::Tensor losses = torch::full({6, 4}, -1.f);
         for (int idx = 0; idx < 6; ++idx) {

@@ -568,6 +568,10 @@ def test_sharded_mapper_with_bundle_adjustment_equals_the_single_process_run(tmp
         for name in ranks[0]:
             assert np.array_equal(ranks[0][name], ranks[k][name]), (k, name)
     got = ranks[0]
+    # the Tracker ran on rank 0 only and its pose went out as a sum with zeros (Dist::broadcast0): every rank holds rank 0's pose (the loop above
+    # compared the files bit for bit), and it is the pose the single process tracked, up to the order of its ray-gradient sums
+    assert got["tracked"].shape == (8,) and got["tracked"][7] == 0 and abs(np.linalg.norm(got["tracked"][:4]) - 1) < 1e-2
+    assert np.abs(got["tracked"] - single["tracked"]).max() < 1e-4, (got["tracked"], single["tracked"])
     assert np.allclose(got["losses"], single["losses"], rtol=2e-5, atol=1e-6), (got["losses"], single["losses"])
     assert got["kept"][0] > 0 and single["ba_grad"].shape == got["ba_grad"].shape
     # bundle-adjustment pose gradients: sums of the same ray gradients in another order

@@ -345,7 +345,7 @@ def quat_cam(c2w):
     return np.concatenate([q, c2w[:3, 3], [0.0]]).astype(np.float32)
 
 
-def run_k5_loop(local, rank, world, dist, comm, cycles=20, warmup=3, track_rays=200, track_iters=10, map_rays=1000, map_iters=12):
+def run_k5_loop(local, rank, world, dist, comm, cycles=20, warmup=3, track_rays=200, track_iters=10, map_rays=1000, map_iters=12, tune=()):
     """BASELINE configs[4] as a loop: per frame of a TUM-fr1/desk-class sequence (bound / camera declared in tests/scenes.py), the Tracker's
     iterations on 200 pixels of the new frame (config/nice_slam.yaml tracking.pixels / iters; on rank 0 only, its pose then goes to every rank: 8
     floats), then the frame's share of the Mapper's iterations (mapping.iters 60 on every 5th frame = 12 per frame) on 1000 pixels of a
@@ -367,6 +367,8 @@ def run_k5_loop(local, rank, world, dist, comm, cycles=20, warmup=3, track_rays=
     depth = [cu(scenes.frame_depth_image(sc["bound"], c, **cam)) for c in c2ws]
     color = [cu(scenes.frame_color_image(sc["bound"], c, **cam)) for c in c2ws]
     ctx = pkg.Context(local)
+    for kv in tune:                                        # experiments: nsk_set_tuning keys (--tune key=value)
+        k_, v_ = kv.split("="); ctx.set_tuning(k_, int(v_))
     for kv in TUNE:
         k, v = kv.split("=")
         ctx.set_sort_mode(int(v)) if k == "sort_mode" else ctx.set_tuning(k, int(v))
@@ -601,7 +603,7 @@ def main():
                 exchange = "nsk_allreduce_grads (pack -> ncclAllReduce -> unpack on the context's stream; RCCL communicator bootstrapped from the process group)"
     pipeline = True if args.pipeline < 0 else bool(args.pipeline)
     if args.k5_only:
-        k5 = run_k5_loop(local, rank, world, dist, comm, cycles=20)
+        k5 = run_k5_loop(local, rank, world, dist, comm, cycles=20, tune=args.tune)
         if rank == 0:
             print(json.dumps(k5))
         if dist is not None:

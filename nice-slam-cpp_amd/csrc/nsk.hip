@@ -1682,7 +1682,7 @@ static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const fl
         size_t lds16 = 0;
         for (int r = 0; r < n; ++r) lds16 = std::max(lds16, MA.which[r] == 0 ? fwd_img_floats(0) * 4 : (size_t)c->dec[MA.which[r]].fimg16_f * 4);
         if (c->matmul_mode == 2) k_decode_fwd_multi_bf16<8, 2><<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);
-        else k_decode_fwd_multi_bf16<8><<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);       // 12 waves (168 VGPRs) spill: 59 -> 71 us (the two-piece form at 12 waves: 50 spilled registers, round 4 compile check)
+        else k_decode_fwd_multi_bf16<8><<<MA.wg_end[n - 1], 512, lds16, c->stream>>>(MA);       // 12 waves (168 VGPRs) spill: 59 -> 71 us (the two-piece form at 12 waves: 50 spilled registers, K3 forward 139 -> 202 us, round 4)
     } else
     k_decode_fwd_multi<<<MA.wg_end[n - 1], 512, lds, c->stream>>>(MA);
     HIPCHK(hipGetLastError());

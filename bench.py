@@ -36,7 +36,7 @@ PEAK_HBM_GBS = 8000.0              # same guide, HBM3E peak
 # these files is labelled "counters_from" in the JSON line -- the durations beside them are always this run's HIP events.
 PMC_FILES = ("r04_pmc_hbm.json", "r03_pmc_hbm.json")
 PMC_SQ_FILES = ("r04_pmc_sq.json", "r03_pmc_sq.json")
-KERNEL_PREFIX = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "void k_decode_fwd_multi_bf16"}
+KERNEL_PREFIX = {"decode_bwd_multi": "void k_decode_bwd_multi<false>", "decode_fwd_multi": "void k_decode_fwd_multi_"}      # (_occ<8>: the merged middle + fine role, round 4; _bf16<8, 2> before)
 
 
 def _first_profile(names):

@@ -797,6 +797,7 @@ struct nsk_ctx {
     bool touched[NSK_NUM_GROUPS] = {false, false, false, false, false, false};
     bool deterministic = false;             // debug: bit-reproducible gradients (see nsk_set_tuning in include/nsk.h)
     bool roctx = false;                     // roctx ranges around every profiled launch group (libroctx64, loaded on demand)
+    int tune_fwd_occ_cost = 0, tune_no_occ_role = 0;         // the merged middle + fine role of the forward: its cost against the colour role's (0 = 460); 1 = never merged, 2 = always
     int tune_fwd_fine_cost = 0, tune_fwd_color_cost = 0;     // experiments: forward role costs (nsk_set_tuning "fwd_fine_cost" / "fwd_color_cost")
     int tune_skew = 0;                      // start offset of the upper four waves of a decoder workgroup, x 1024 cycles (wave_skew, nsk_device.h)
     bool median_fused_pending = false;
@@ -932,7 +933,7 @@ extern "C" int nsk_ctx_create(int device, void* hip_stream, nsk_ctx** out)
     SETB(0) SETB(1) SETB(2) SETB(3)
 #undef SETB
     CHK(set_lds(k_median_thr, 16384 * 4));
-    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8, 2>, 160 * 1024));
+    CHK(set_lds(k_decode_fwd_multi, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_bf16<8, 2>, 160 * 1024)); CHK(set_lds(k_decode_fwd_multi_occ<8>, 160 * 1024));
     CHK(set_lds(k_decode_bwd_multi<false>, 160 * 1024 - 256)); CHK(set_lds(k_decode_bwd_multi<true>, 160 * 1024));      // (<false>, frozen: the scan role keeps a few words of static LDS)
     CHK(set_lds(k_decode_bwd_frozen<false>, 160 * 1024 - 256));
     CHK(set_lds(k_decode_bwd_track, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi_full<false>, 160 * 1024)); CHK(set_lds(k_decode_bwd_multi_full<true>, 160 * 1024));
@@ -1022,6 +1023,8 @@ extern "C" int nsk_set_tuning(nsk_ctx* c, const char* key, int value)
     if (!strcmp(key, "no_fused_median")) { c->tune_no_fused_median = value; return 0; }
     if (!strcmp(key, "no_deferred_median")) { c->tune_no_deferred_median = value; return 0; }
     if (!strcmp(key, "fwd_fine_cost")) { c->tune_fwd_fine_cost = value; return 0; }
+    if (!strcmp(key, "fwd_occ_cost")) { c->tune_fwd_occ_cost = value; return 0; }
+    if (!strcmp(key, "no_occ_role")) { c->tune_no_occ_role = value; return 0; }
     if (!strcmp(key, "fwd_color_cost")) { c->tune_fwd_color_cost = value; return 0; }
     if (!strcmp(key, "skew")) { if (value < 0 || value > 299) return fail("nsk_set_tuning: skew out of range"); c->tune_skew = value; return 0; }
     if (!strcmp(key, "deterministic")) { c->deterministic = value != 0; return 0; }
@@ -1656,6 +1659,17 @@ static void split_wgs_train(int num_cu, int ntasks, int n, const int* cost, int 
     }
 }
 
+// predicted time of a split in the cost units of its roles: every wave of a role walks ceil(tiles / waves) tiles
+static long split_makespan(int ntasks, int n, const int* cost, const int* wg_end, int waves = 8)
+{
+    long t = 0;
+    for (int r = 0; r < n; ++r) {
+        const int w = std::max(1, wg_end[r] - (r ? wg_end[r - 1] : 0));
+        t = std::max(t, (long)((ntasks + waves * w - 1) / (waves * w)) * cost[r]);
+    }
+    return t;
+}
+
 // all decoders of the stage in ONE launch (workgroup roles), or a plain launch when the stage has one decoder
 static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const float* ro, const float* rd, bool save_masks)
 {
@@ -1665,6 +1679,43 @@ static int launch_decode_fwd_stage(nsk_ctx* c, int stage, int M, int S, const fl
     static const int fcost[4] = {96, 240, 292, 248};      // issue cycles per tile of the roles (coarse fp32; middle 7 560, fine 9 380, colour 7 710 + its block-output stores)
     MultiArgs MA;
     memset(&MA, 0, sizeof(MA));
+    // middle + fine as ONE role (decode_fwd_occ_body: the middle level looked up once): frozen occupancy decoders on two-piece operands
+    if (c->matmul_mode == 2 && c->tune_no_occ_role != 1 && STAGE_DEC[stage][0] == 1 && STAGE_DEC[stage][1] == 2 && !saves_h(c, 1, save_masks) && !saves_h(c, 2, save_masks)) {
+        const bool colour = STAGE_DEC[stage][2] == 3;
+        for (int r = 0; r < (colour ? 3 : 2); ++r) {
+            const int w = STAGE_DEC[stage][r];
+            fill_args(c, MA.a[r], w, M, S, ro, rd, nullptr);
+            MA.a[r].masks = save_masks ? c->ws.masks[w] : nullptr;
+            if (save_masks) c->ws.hsave_M[w] = 0;
+            MA.which[r] = w;
+        }
+        if (colour && saves_h(c, 3, save_masks)) { CHK(ensure_hsave(c, 3, M)); MA.a[2].hsave = c->ws.hsave[3]; c->ws.hsave_M[3] = M; }
+        int cost[2] = {c->tune_fwd_occ_cost > 0 ? c->tune_fwd_occ_cost : 460, c->tune_fwd_color_cost > 0 ? c->tune_fwd_color_cost : fcost[3]};
+        MA.n = colour ? 2 : 1;
+        split_wgs_balanced(c->num_cu, (M + 15) / 16, MA.n, cost, MA.wg_end, 8);
+        if (!colour) MA.wg_end[1] = MA.wg_end[0];
+        // A merged tile is two decoders long, so small batches quantise worse (K2: 3 000 tiles on 256 workgroups -- forward 37.7 us as three roles,
+        // 40.2 as two): take the form whose split predicts the shorter launch.  (tune_no_occ_role 2: always merged)
+        bool merged = true;
+        if (c->tune_no_occ_role != 2) {
+            int cost3[3], wg3[3], n3 = colour ? 3 : 2;
+            for (int r = 0; r < n3; ++r) {
+                const int w = STAGE_DEC[stage][r];
+                cost3[r] = (w == 2 && c->tune_fwd_fine_cost > 0) ? c->tune_fwd_fine_cost : ((w == 3 && c->tune_fwd_color_cost > 0) ? c->tune_fwd_color_cost : fcost[w]);
+            }
+            split_wgs_balanced(c->num_cu, (M + 15) / 16, n3, cost3, wg3, 8);
+            merged = split_makespan((M + 15) / 16, MA.n, cost, MA.wg_end) <= split_makespan((M + 15) / 16, n3, cost3, wg3);
+        }
+        if (merged) {
+            size_t lds_occ = ((size_t)c->dec[1].fimg16_f + (size_t)c->dec[2].fimg16_f) * 4;
+            if (colour) lds_occ = std::max(lds_occ, (size_t)c->dec[3].fimg16_f * 4);
+            ProfScope ps(c, "decode_fwd_multi");
+            k_decode_fwd_multi_occ<8><<<MA.wg_end[MA.n - 1], 512, lds_occ, c->stream>>>(MA);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
+        memset(&MA, 0, sizeof(MA));
+    }
     int cost[3]; size_t lds = 0;
     for (int r = 0; r < n; ++r) {
         int w = STAGE_DEC[stage][r];

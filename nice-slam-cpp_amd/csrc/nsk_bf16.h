@@ -240,6 +240,95 @@ __device__ __forceinline__ void decode_fwd_bf16_body(const DecArgs& A, int bid, 
     }
 }
 
+// The two occupancy decoders of a stage (middle, fine) as ONE role over the same tiles (round 4): the fine decoder's input is fine || middle
+// features (reference src/models/NICE.cpp:40-49), so as two roles the middle level was looked up twice -- tri_setup and a 16-load gather in each
+// role, the fine role's second gather the one load chain of the forward that nothing overlapped -- and the sample was loaded and finished twice.
+// Here: both weight images in LDS (64 + 85 KB), the middle gather flies under the middle embedding, the fine gather under the fine embedding, the
+// middle features stay in registers for the fine chain.  Each decoder's own arithmetic is the two-role form's, instruction for instruction
+// (tools/ab_outputs.py: same digests).  Frozen decoders only (no block-output stores); fp16 two-piece operands (matmul mode 2).
+template <int NW>
+__device__ __forceinline__ void decode_fwd_occ_body(const DecArgs& Am, const DecArgs& Af, int bid, int nb)
+{
+    typedef MlpFwdImgB<2, 2> IM;
+    typedef MlpFwdImgB<4, 2> IF;
+    extern __shared__ __attribute__((aligned(16))) f4 smem[];
+    copy_image_to_lds<64 * NW>(smem, reinterpret_cast<const f4*>(Am.img16), IM::TOTAL_F / 4);
+    copy_image_to_lds<64 * NW>(smem + IM::TOTAL_F / 4, reinterpret_cast<const f4*>(Af.img16), IF::TOTAL_F / 4);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const float* imgf_m = reinterpret_cast<const float*>(smem);
+    const float* imgf_f = imgf_m + IM::TOTAL_F;
+    const h8* img_m = reinterpret_cast<const h8*>(imgf_m);
+    const h8* img_f = reinterpret_cast<const h8*>(imgf_f);
+    const int ntasks = (Af.M + 15) >> 4;
+    const int nw = nb * NW, wg = bid * NW + wave;
+    const int tsh = tile_shift(ntasks, nw);
+    const int kmax = tiles_per_wave(ntasks, nw, tsh);
+    SampleRaw nx;
+    int m = slot_sample(Af, tile_of(0, wg, nw, tsh) * 16 + j);
+    sample_load(Af, m, nx);
+    int m_next = slot_sample(Af, tile_of(1, wg, nw, tsh) * 16 + j);
+    wave_skew(Af, wave, NW);
+    for (int k = 0; k < kmax; ++k) {
+        const int task = tile_of(k, wg, nw, tsh);
+        if (task >= ntasks) break;
+        asm volatile("" ::: "memory");
+        const int slot = task * 16 + j;
+        float px, py, pz;
+        sample_finish(Af, nx, px, py, pz);
+        f4 dummy[6];
+        f4 xm0, xm1;                                       // the middle level's features of the sample: the middle decoder's input and half of the fine one's
+        unsigned long long mask_m;
+        {
+            Tri T;
+            tri_setup(Am.grid, Am.bound, px, py, pz, T);
+            Act<2> C;
+            GatherRaw R;
+            tri_gather_issue<true>(Am.grid, T, g, R);
+            sample_load(Af, m_next, nx);                   // unconditional (clamped): no branch, no wait here
+            embed<false>(imgf_m + IM::P_BM, g, px, py, pz, C.xe, dummy);
+            asm volatile("" ::: "memory");                 // keep the order: loads, embedding, weighting
+            tri_gather_reduce(T, R, xm0, xm1);
+            C.xc[0] = xm0; C.xc[1] = xm1;
+            mlp_forward_f16<2>(img_m, imgf_m, lane, C);
+            float out[1];
+            mlp_output<1>(imgf_m + IM::P_WO, imgf_m + IM::P_BO, g, C.h[4], out);
+            if (slot < Am.M && g == 0) Am.out[(unsigned)m] = out[0];
+            mask_m = C.mask;
+        }
+        const int m_cur = m;
+        m = m_next;
+        m_next = slot_sample(Af, tile_of(k + 2, wg, nw, tsh) * 16 + j);
+        {
+            Tri T;
+            tri_setup(Af.grid, Af.bound, px, py, pz, T);
+            Act<4> C;
+            GatherRaw R;
+            tri_gather_issue<true>(Af.grid, T, g, R);
+            embed<false>(imgf_f + IF::P_BM, g, px, py, pz, C.xe, dummy);
+            asm volatile("" ::: "memory");
+            tri_gather_reduce(T, R, C.xc[0], C.xc[1]);
+            C.xc[2] = xm0; C.xc[3] = xm1;
+            mlp_forward_f16<4>(img_f, imgf_f, lane, C);
+            float out[1];
+            mlp_output<1>(imgf_f + IF::P_WO, imgf_f + IF::P_BO, g, C.h[4], out);
+            if (slot < Af.M) {
+                if (g == 0) Af.out[(unsigned)m_cur] = out[0];
+                if (Af.masks) Af.masks[(unsigned)slot * 4u + (unsigned)g] = C.mask;
+                if (Am.masks) Am.masks[(unsigned)slot * 4u + (unsigned)g] = mask_m;
+            }
+        }
+    }
+}
+
+// roles: [0, wg_end[0]) the merged occupancy role on (a[0] = middle, a[1] = fine); [wg_end[0], wg_end[1]) the colour decoder on a[2] (MA.n == 2) or nothing
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_decode_fwd_multi_occ(MultiArgs MA)
+{
+    if ((int)blockIdx.x < MA.wg_end[0]) decode_fwd_occ_body<NW>(MA.a[0], MA.a[1], blockIdx.x, MA.wg_end[0]);
+    else decode_fwd_bf16_body<3, NW, 2>(MA.a[2], (int)blockIdx.x - MA.wg_end[0], MA.wg_end[1] - MA.wg_end[0]);
+}
+
 template <int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW) void k_decode_fwd_multi_bf16(MultiArgs MA)
 {

@@ -101,7 +101,9 @@ int nsk_set_sort_mode(nsk_ctx* ctx, int mode);
  *                      even where a fused form applies;
  *   "no_deferred_median" 1: with ray gradients and frozen decoders the threshold is found inside the compositing launch behind a grid
  *                      barrier (round 3's form) instead of by the backward launch's workgroups;
- *   "no_piggyback" 1:  a batch registered with nsk_map_prepare is sampled by launches of its own at the start of its step. */
+ *   "no_piggyback" 1:  a batch registered with nsk_map_prepare is sampled by launches of its own at the start of its step;
+ *   "no_occ_role" 1 | 2: the forward's middle and fine decoders never | always as one workgroup role (default: where the split predicts
+ *                      the shorter launch; same results either way). */
 int nsk_set_tuning(nsk_ctx* ctx, const char* key, int value);
 
 /* Scene bound [[x0,x1],[y0,y1],[z0,z1]]; the reference hard-codes it in five places

@@ -739,3 +739,32 @@ def test_sample_counts_that_are_not_multiples_of_the_tile(n_samples, n_surface, 
     assert rel_l2(ctx.decoder_download("color", grad=True), ref["g_decoders"]["color"]) < TOL
     assert rel_l2(g_ro.cpu().numpy(), ref["g_rays_o"]) < TOL and rel_l2(g_rd.cpu().numpy(), ref["g_rays_d"]) < TOL
     ctx.close()
+
+
+@pytest.mark.parametrize("stage", ["fine", "color"])
+@pytest.mark.parametrize("n_rays", [1, 7, 100, 333])
+def test_forward_merged_occupancy_role_has_the_bits_of_the_separate_roles(stage, n_rays):
+    """The forward's middle and fine decoders as ONE workgroup role (decode_fwd_occ_body: the middle level looked up once, both weight images in
+    LDS) against the three-role launch, each forced by nsk_set_tuning("no_occ_role", 2 | 1) -- the host otherwise takes whichever split
+    predicts the shorter launch, so at these ragged sizes (a single ray, partial tiles, rays without depth, both sample orders) the merged body
+    would not run by itself.  Each decoder's arithmetic is the same instruction sequence in both forms: rendered arrays, the per-sample decoder
+    outputs and the ReLU bits a mapping step saves must agree bit for bit."""
+    sc = _scene(41, grid_std=0.3)
+    rays = scenes.make_rays(42, n_rays, sc["bound"], n_frames=1, zero_frac=0.2)
+    got = {}
+    for form in (1, 2):
+        for sort_mode in (0, 1):
+            ctx = make_ctx(sc, trainable=["color"] if stage == "color" else [])
+            ctx.set_tuning("no_occ_role", form)
+            ctx.set_sort_mode(sort_mode)
+            ro, rd, gd, gc = cu(rays["rays_o"]), cu(rays["rays_d"]), cu(rays["gt_depth"]), cu(rays["gt_color"])
+            rgb, depth, var, w = ctx.render_forward(stage, ro, rd, gd)
+            loss = torch.zeros(1, device="cuda")
+            ctx.map_step(stage, ro, rd, gd, gc, -1.0, 0.5, True, flags=3, loss=loss)
+            ctx.sync()
+            M = n_rays * w.shape[1]
+            got[form, sort_mode] = [rgb.cpu().numpy(), depth.cpu().numpy(), var.cpu().numpy(), w.cpu().numpy(), np.float32(float(loss)),
+                                    ctx.debug_fetch("occ1", M), ctx.debug_fetch("occ2", M), ctx.debug_relu_bits("middle", M), ctx.debug_relu_bits("fine", M)]
+    for sort_mode in (0, 1):
+        for a, b in zip(got[1, sort_mode], got[2, sort_mode]):
+            assert np.array_equal(a, b, equal_nan=True), (stage, n_rays, sort_mode)

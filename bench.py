@@ -202,7 +202,7 @@ TUNE = []
 
 
 def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=False, frustum=True, matmul_mode=None, pipeline=False,
-                 comm=None, rays_total=None, repeats=1, backward_mode=None):
+                 comm=None, rays_total=None, repeats=1, backward_mode=None, forward_only=False):
     """time `steps` mapping iterations of workload `wl` at `N` rays per GPU (rays_total: a FIXED batch of that many rays sharded over
     the ranks instead -- strong scaling); returns dict(dt, prof, loss, scene, pool, ...).  comm: an RCCL communicator for the C-ABI
     exchange (nsk_allreduce_grads), None = torch.distributed on the packed buffer"""
@@ -262,6 +262,9 @@ def run_workload(wl, stage, N, steps, warmup, local, rank, world, dist, graph=Fa
 
         def step(i):
             ro, rd, gd, gc, gmax = batches[i % len(batches)]
+            if forward_only:                                     # SURVEY 8(d)'s second figure: Renderer::render_batch_ray alone (sampling, decoders, compositing)
+                ctx.render_forward(stage, ro, rd, gd, gmax, want_weights=False)
+                return
             if pipeline and not graph:                           # the next batch is registered first: its sampling + cell sort ride in this step's
                 nro, nrd, ngd, _, ngmax = batches[(i + 1) % len(batches)]      # composite / backward / Adam launches (nsk_map_prepare)
                 ctx.map_prepare(stage, nro, nrd, ngd, ngmax, flags=flags)
@@ -670,6 +673,8 @@ def main():
                      ("K3_color_mode1", "K3", "color", dict(N=W["K3"]["rays"], matmul_mode=1), 100),
                      ("K3_color_backward_fp32", "K3", "color", dict(N=W["K3"]["rays"], backward_mode=0), 100),
                      ("K3_color_no_mask", "K3", "color", dict(N=W["K3"]["rays"], frustum=False), 100),
+                     ("K3_color_forward_only", "K3", "color", dict(N=W["K3"]["rays"], forward_only=True, pipeline=False), 200),
+                     ("K2_color_forward_only", "K2", "color", dict(N=W["K2"]["rays"], forward_only=True, pipeline=False), 300),
                      ("K3_pipeline_%s" % ("off" if pipeline else "on"), "K3", "color", dict(N=W["K3"]["rays"], pipeline=not pipeline), 200)]
         else:
             plan += [("K4_strong_10000_rays", "K4", "color", dict(N=0, rays_total=10000), 300), ("K2_color", "K2", "color", dict(N=W["K2"]["rays"]), 300),
@@ -683,6 +688,14 @@ def main():
             kw.setdefault("pipeline", pipeline)
             r = run_workload(W[wname], stage, n, k, 20, local, rank, world, dist, comm=comm, **kw)
             if rank != 0:
+                continue
+            if kw.get("forward_only"):                               # no backward launch to price: the line is time and launches only
+                ms = 1e3 * r["dt"] / k
+                extras[name] = {"workload": W[wname]["name"], "stage": stage, "rays_per_gpu": r["rays_per_gpu"], "steps": k,
+                                "value": r["rays_per_gpu"] * world / (1e-3 * ms), "unit": "rays/s", "ms_per_step": ms,
+                                "kernels_avg_us": {kk: round(1e3 * t / c, 2) for kk, (c, t) in r["prof"].items()},
+                                "what": "forward only: nsk_render_forward = Renderer::render_batch_ray (z sampling, cell sort where it pays, all decoders of the "
+                                        "stage, compositing; no loss, backward or Adam) -- SURVEY 8(d)'s forward-only rays/s"}
                 continue
             sm = summarize(r, stage, r["rays_per_gpu"], k, world)
             extras[name] = extra_line(name, W[wname], stage, r, sm, k)

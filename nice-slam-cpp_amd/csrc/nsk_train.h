@@ -976,7 +976,7 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
     auto stage_b1 = [&](Staged& S_) {
         sample_finish(A, S_.r, S_.px, S_.py, S_.pz);
         tri_setup(A.grid, A.bound, S_.px, S_.py, S_.pz, Tn);
-        tri_gather_issue(A.grid, Tn, g, GR);
+        tri_gather_issue<true>(A.grid, Tn, g, GR);
     };
     auto stage_b2 = [&](Staged& S_) { tri_gather_reduce(Tn, GR, S_.xc[0], S_.xc[1]); };
     int mm_next = 0;

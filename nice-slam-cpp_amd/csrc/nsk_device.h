@@ -861,6 +861,11 @@ __device__ __forceinline__ void wave_skew(const DecArgs& A, int wave, int nw)
 }
 
 // ray of sample mm = mm / S without the generic division (~25 vector instructions): umulhi by ceil(2^32 / S), exact for mm < 2^32 / S
+// a load at base + a 32-bit BYTE offset: scalar base, one unsigned vector offset -- no sign extension and no 64-bit shift-add per access (an
+// `int` index costs v_ashrrev + v_lshl_add_u64; k_decode_bwd_multi held ~800 + ~1000 of them).  The caller's offset must stay below 2^32: the
+// host keeps M below 2^26 samples, so sample-indexed arrays of up to 32 bytes per sample qualify (z 4, g_raw 16, ReLU bits 32, perm 4, rays 12).
+template <typename T>
+__device__ __forceinline__ T ld32(const void* base, unsigned byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
 __device__ __forceinline__ int ray_of(const DecArgs& A, int mm) { return A.S_magic ? (int)__umulhi((unsigned)mm, A.S_magic) : mm; }
 struct __attribute__((packed, aligned(4))) Ray3 { float x, y, z; };
 __device__ __forceinline__ void sample_point(const DecArgs& A, int mm, float& px, float& py, float& pz, float& zz, int& n)
@@ -890,11 +895,11 @@ __device__ __forceinline__ void sample_load(const DecArgs& A, int mm, SampleRaw&
     NSK_IDX(1, mm, A.M);
     const int n = ray_of(A, mm);     // = mm / A.S
     NSK_IDX(4, n, (A.M + A.S - 1) / A.S);
-    R.z = A.z[mm];
+    R.z = ld32<float>(A.z, (unsigned)mm * 4u);
     // a ray's origin and direction as ONE 12-byte load each (global_load_dwordx3 needs dword alignment only): the 16 samples of a cell-sorted tile
     // come from 16 rays, so every load instruction touches 16 cache lines, and seven of them per tile and wave kept the CU's address unit busy
     // for ~2 500 cycles of a trainable iteration (tools/exp_ph3.py: the stage_a segment); three do the same work
-    const Ray3 o = *reinterpret_cast<const Ray3*>(A.rays_o + 3 * n), d = *reinterpret_cast<const Ray3*>(A.rays_d + 3 * n);
+    const Ray3 o = ld32<Ray3>(A.rays_o, (unsigned)n * 12u), d = ld32<Ray3>(A.rays_d, (unsigned)n * 12u);
     R.o[0] = o.x; R.o[1] = o.y; R.o[2] = o.z; R.d[0] = d.x; R.d[1] = d.y; R.d[2] = d.z;
 }
 __device__ __forceinline__ void sample_finish(const DecArgs& A, const SampleRaw& R, float& px, float& py, float& pz)
@@ -915,7 +920,7 @@ __device__ __forceinline__ int slot_sample(const DecArgs& A, int slot)
 #ifdef NSK_EXPERIMENT
     if (A.perm) { const int v = A.perm[s]; NSK_IDX(0, v, A.M); return v; }
 #endif
-    return A.perm ? A.perm[s] : s;
+    return A.perm ? ld32<int>(A.perm, (unsigned)s * 4u) : s;
 }
 
 // Tile schedule shared by the decoder kernels: wave `wg` of `nw` takes blocks of 2^sh consecutive tiles, dealt round-robin over the
@@ -1553,8 +1558,8 @@ __device__ __forceinline__ void decode_bwd_body(const DecArgs& A, int bid, int n
         const int sl_ = slot_of(task_);
         NSK_IDX(2, sl_, A.M);
         sample_load(A, mm_, S_.r);
-        S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm_ * 4);
-        S_.mask = A.masks[(size_t)sl_ * 4 + g];
+        S_.gr = ld32<f4>(A.g_raw, (unsigned)mm_ * 16u);
+        S_.mask = ld32<unsigned long long>(A.masks, ((unsigned)sl_ * 4u + (unsigned)g) * 8u);
         S_.mm = mm_;
     };
     const int nw = nb * NW, wg = bid * NW + wave;

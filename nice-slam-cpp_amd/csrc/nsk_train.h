@@ -966,10 +966,10 @@ __device__ __forceinline__ void decode_bwd_train_m_body(const DecArgs& A, int bi
         S_.valid = slot < A.M;
         S_.mm = mm;
         if (!NSK_DBG(A, 10)) sample_load(A, mm, S_.r);                       // (experiment bits 10, 11, 15: which of these loads stalls the issue -- tools/exp_ph3.py)
-        if (!NSK_DBG(A, 11)) S_.gr = *reinterpret_cast<const f4*>(A.g_raw + (size_t)mm * 4);
+        if (!NSK_DBG(A, 11)) S_.gr = ld32<f4>(A.g_raw, (unsigned)mm * 16u);
         const int tk = min(task, ntasks - 1);
         NSK_IDX(3, tk, ntasks); NSK_IDX(2, min(slot, A.M - 1), A.M);
-        if (!NSK_DBG(A, 11)) S_.mask = A.masks[(size_t)min(slot, A.M - 1) * 4 + g];
+        if (!NSK_DBG(A, 11)) S_.mask = ld32<unsigned long long>(A.masks, ((unsigned)min(slot, A.M - 1) * 4u + (unsigned)g) * 8u);
         if (!NSK_DBG(A, 15)) { S_.h4[0] = A.hsave[((size_t)tk * 10 + 8) * 64 + lane]; S_.h4[1] = A.hsave[((size_t)tk * 10 + 9) * 64 + lane]; }
     };
     Tri Tn; GatherRaw GR;                                // the next tile's cell and its corner lines in flight
